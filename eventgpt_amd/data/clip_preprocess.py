@@ -1,0 +1,150 @@
+"""CLIP image preprocessing for event rasters.
+
+Pipeline (reference: common/common.py:123-127, which calls HF
+``CLIPImageProcessor``): resize so the *shortest* edge is 336 (PIL bicubic with
+antialiasing, uint8 in / uint8 out), centre-crop 336², scale by 1/255, normalise
+with the CLIP mean/std.
+
+The resampling is specified here as integer coefficient tables that match
+PIL's two-pass fixed-point resampler bit for bit (horizontal pass, uint8
+rounding, vertical pass, uint8 rounding; 22 fractional bits).  The same tables
+drive the numpy implementation in this file and the fused HIP kernel
+(``eventgpt_amd/csrc/kernels/clip_preproc.hip``), so host and device paths
+agree exactly on the uint8 image.
+"""
+from __future__ import annotations
+
+import dataclasses
+import functools
+import math
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from ..constants import CLIP_IMAGE_SIZE, CLIP_MEAN, CLIP_STD
+
+PRECISION_BITS = 32 - 8 - 2  # PIL's fixed-point precision for 8-bit resampling
+
+
+def _bicubic(x: np.ndarray, a: float = -0.5) -> np.ndarray:
+    x = np.abs(x)
+    return np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0,
+                    np.where(x < 2.0, (((x - 5.0) * x + 8.0) * x - 4.0) * a, 0.0))
+
+
+@dataclasses.dataclass(frozen=True)
+class ResampleTable:
+    """Per-output-coordinate tap window and fixed-point weights."""
+    start: np.ndarray   # [out]  int32 first input index
+    count: np.ndarray   # [out]  int32 number of taps
+    weight: np.ndarray  # [out, ksize] int32 fixed-point weights (zero padded)
+
+    @property
+    def ksize(self) -> int:
+        return self.weight.shape[1]
+
+
+@functools.lru_cache(maxsize=64)
+def resample_table(in_size: int, out_size: int) -> ResampleTable:
+    """Antialiased bicubic taps for resizing ``in_size`` → ``out_size``."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    start = np.zeros(out_size, np.int32)
+    count = np.zeros(out_size, np.int32)
+    weight = np.zeros((out_size, ksize), np.int32)
+    inv = 1.0 / filterscale
+    for o in range(out_size):
+        center = (o + 0.5) * scale
+        lo = max(int(center - support + 0.5), 0)
+        hi = min(int(center + support + 0.5), in_size)
+        n = hi - lo
+        k = _bicubic((np.arange(n) + lo - center + 0.5) * inv)
+        s = k.sum()
+        if s != 0.0:
+            k = k / s
+        fixed = np.where(k < 0, (k * (1 << PRECISION_BITS) - 0.5),
+                         (k * (1 << PRECISION_BITS) + 0.5)).astype(np.int64)
+        start[o], count[o] = lo, n
+        weight[o, :n] = fixed
+    return ResampleTable(start, count, weight)
+
+
+def resized_shape(h: int, w: int, shortest: int = CLIP_IMAGE_SIZE) -> Tuple[int, int]:
+    """Output ``(H, W)`` when the shortest edge becomes ``shortest``."""
+    short, long_ = (h, w) if h <= w else (w, h)
+    new_long = int(shortest * long_ / short)
+    return (shortest, new_long) if h <= w else (new_long, shortest)
+
+
+def _clip8(acc: np.ndarray) -> np.ndarray:
+    return np.clip(acc >> PRECISION_BITS, 0, 255).astype(np.uint8)
+
+
+def resize_bicubic_u8(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """Two-pass fixed-point bicubic resize of an ``H×W×C`` uint8 image."""
+    h, w, _ = img.shape
+    half = 1 << (PRECISION_BITS - 1)
+    src = img.astype(np.int64)
+    if out_w != w:
+        tab = resample_table(w, out_w)
+        idx = np.minimum(tab.start[:, None] + np.arange(tab.ksize)[None, :], w - 1)
+        # [H, out_w, k, C] · [out_w, k] -> [H, out_w, C]
+        acc = np.einsum("hokc,ok->hoc", src[:, idx, :], tab.weight.astype(np.int64)) + half
+        src = _clip8(acc).astype(np.int64)
+    if out_h != h:
+        tab = resample_table(h, out_h)
+        idx = np.minimum(tab.start[:, None] + np.arange(tab.ksize)[None, :], h - 1)
+        acc = np.einsum("okwc,ok->owc", src[idx, :, :], tab.weight.astype(np.int64)) + half
+        src = _clip8(acc).astype(np.int64)
+    return src.astype(np.uint8)
+
+
+def center_crop_offsets(h: int, w: int, crop: int = CLIP_IMAGE_SIZE) -> Tuple[int, int]:
+    return (h - crop) // 2, (w - crop) // 2
+
+
+def preprocess_image(img: np.ndarray, size: int = CLIP_IMAGE_SIZE) -> np.ndarray:
+    """``H×W×3`` uint8 → ``3×size×size`` float32, CLIP-normalised."""
+    if img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
+        raise ValueError("expected an HxWx3 uint8 image")
+    h, w, _ = img.shape
+    rh, rw = resized_shape(h, w, size)
+    small = resize_bicubic_u8(img, rh, rw)
+    if rh < size or rw < size:
+        raise ValueError("image too small to crop after resize")
+    top, left = center_crop_offsets(rh, rw, size)
+    crop = small[top:top + size, left:left + size].astype(np.float32)
+    mean = np.asarray(CLIP_MEAN, np.float32)
+    std = np.asarray(CLIP_STD, np.float32)
+    out = (crop * np.float32(1.0 / 255.0) - mean) / std
+    return np.ascontiguousarray(out.transpose(2, 0, 1))
+
+
+class EventImageProcessor:
+    """Stand-in for the reference's ``event_processor`` attribute.
+
+    Call signature follows the image-processor convention used by callers
+    (``proc(img, return_tensors='pt')['pixel_values'][0]``) so existing
+    harness code keeps working.
+    """
+
+    def __init__(self, size: int = CLIP_IMAGE_SIZE):
+        self.size = size
+        self.crop_size = {"height": size, "width": size}
+        self.image_mean = list(CLIP_MEAN)
+        self.image_std = list(CLIP_STD)
+
+    def preprocess(self, images, return_tensors=None):
+        if not isinstance(images, (list, tuple)):
+            images = [images]
+        arrs = [preprocess_image(np.asarray(im.convert("RGB")) if hasattr(im, "convert")
+                                 else np.asarray(im), self.size) for im in images]
+        batch = np.stack(arrs)
+        if return_tensors == "pt":
+            import torch
+            batch = torch.from_numpy(batch)
+        return {"pixel_values": batch}
+
+    __call__ = preprocess
