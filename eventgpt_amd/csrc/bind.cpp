@@ -1,0 +1,374 @@
+// torch op registration for the gfx950 kernels (namespace `evgpt::`).
+//
+// Two kinds of ops:
+//   * functional ops (rmsnorm, linear, attention, ...) that allocate their
+//     output — used by the nn.Module path;
+//   * in-place "engine" ops that read and write caller-owned static buffers and
+//     take device-resident positions — used by the serving engine and safe to
+//     capture into a hipGraph (no allocation, no host sync).
+// Host-side shape checks live here so a kernel is never launched on operands
+// that do not match what its indexing assumes.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include "evgpt_kernels.h"
+
+namespace {
+
+using at::Tensor;
+using evgpt::bf16_t;
+
+hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(); }
+
+const bf16_t* bptr(const Tensor& t) { return reinterpret_cast<const bf16_t*>(t.data_ptr()); }
+bf16_t* bptr_mut(const Tensor& t) { return reinterpret_cast<bf16_t*>(t.data_ptr()); }
+const bf16_t* bptr_opt(const c10::optional<Tensor>& t) {
+  return t.has_value() && t->defined() ? bptr(*t) : nullptr;
+}
+
+void check_bf16(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda(), name, " must be a GPU tensor");
+  TORCH_CHECK(t.scalar_type() == at::kBFloat16, name, " must be bfloat16");
+  TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
+  TORCH_CHECK((reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) == 0, name, " must be 16-byte aligned");
+}
+void check_i32(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kInt && t.is_contiguous(), name,
+              " must be a contiguous int32 GPU tensor");
+}
+void check_f32(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat && t.is_contiguous(), name,
+              " must be a contiguous float32 GPU tensor");
+}
+
+// ------------------------------------------------------------------ norms
+Tensor rmsnorm(const Tensor& x, const Tensor& w, double eps) {
+  check_bf16(x, "x"); check_bf16(w, "weight");
+  const int64_t H = x.size(-1);
+  TORCH_CHECK(H % 8 == 0 && w.numel() == H, "rmsnorm: hidden size must be a multiple of 8");
+  Tensor y = at::empty_like(x);
+  const int64_t rows = x.numel() / H;
+  if (rows > 0)
+    evgpt::launch_rmsnorm(bptr(x), nullptr, bptr(w), bptr_mut(y), nullptr, (int)rows, (int)H,
+                          (float)eps, cur_stream());
+  return y;
+}
+
+std::tuple<Tensor, Tensor> add_rmsnorm(const Tensor& x, const Tensor& res, const Tensor& w,
+                                       double eps) {
+  check_bf16(x, "x"); check_bf16(res, "residual"); check_bf16(w, "weight");
+  TORCH_CHECK(x.sizes() == res.sizes(), "add_rmsnorm: shape mismatch");
+  const int64_t H = x.size(-1);
+  TORCH_CHECK(H % 8 == 0 && w.numel() == H);
+  Tensor y = at::empty_like(x), r = at::empty_like(x);
+  const int64_t rows = x.numel() / H;
+  if (rows > 0)
+    evgpt::launch_rmsnorm(bptr(x), bptr(res), bptr(w), bptr_mut(y), bptr_mut(r), (int)rows, (int)H,
+                          (float)eps, cur_stream());
+  return {y, r};
+}
+
+Tensor layernorm(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, double eps) {
+  check_bf16(x, "x"); check_bf16(w, "weight");
+  if (b.has_value()) check_bf16(*b, "bias");
+  const int64_t H = x.size(-1);
+  TORCH_CHECK(H % 8 == 0 && w.numel() == H);
+  Tensor y = at::empty_like(x);
+  const int64_t rows = x.numel() / H;
+  if (rows > 0)
+    evgpt::launch_layernorm(bptr(x), bptr(w), bptr_opt(b), bptr_mut(y), (int)rows, (int)H,
+                            (float)eps, cur_stream());
+  return y;
+}
+
+// ------------------------------------------------------------------ linear
+// y = act(x @ w^T + bias) + res.  rows <= 4 -> weight-streaming GEMV, else MFMA GEMM.
+Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias,
+              const c10::optional<Tensor>& res, int64_t act, bool out_f32) {
+  check_bf16(x, "x"); check_bf16(w, "weight");
+  TORCH_CHECK(w.dim() == 2, "weight must be [N, K]");
+  const int64_t K = x.size(-1), N = w.size(0);
+  TORCH_CHECK(w.size(1) == K, "linear: K mismatch (", w.size(1), " vs ", K, ")");
+  TORCH_CHECK(K % 8 == 0, "linear: K must be a multiple of 8");
+  const int64_t M = x.numel() / K;
+  if (bias.has_value()) { check_bf16(*bias, "bias"); TORCH_CHECK(bias->numel() == N); }
+  auto out_sizes = x.sizes().vec();
+  out_sizes.back() = N;
+  if (res.has_value()) {
+    check_bf16(*res, "residual");
+    TORCH_CHECK(res->numel() == M * N, "linear: residual shape mismatch");
+  }
+  Tensor y = at::empty(out_sizes, x.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
+  if (M == 0) return y;
+  auto st = cur_stream();
+  const bool gemv_ok = M <= evgpt::gemv_max_batch() && !out_f32 && N % 4 == 0 &&
+                       (int64_t)M * K * 2 <= 96 * 1024;
+  if (gemv_ok) {
+    evgpt::launch_gemv(bptr(w), bptr(x), bptr_mut(y), bptr_opt(bias), bptr_opt(res), nullptr, 0.f,
+                       (int)act, (int)M, (int)N, (int)K, st);
+  } else {
+    TORCH_CHECK(K % 64 == 0, "linear: the MFMA GEMM needs K % 64 == 0 (pad the operands)");
+    evgpt::launch_gemm_bf16(bptr(x), bptr(w), out_f32 ? nullptr : bptr_mut(y),
+                            out_f32 ? y.data_ptr<float>() : nullptr, bptr_opt(bias),
+                            bptr_opt(res), (int)M, (int)N, (int)K, (int)K, (int)K, (int)N, (int)act,
+                            st);
+  }
+  return y;
+}
+
+Tensor swiglu(const Tensor& gate_up) {
+  check_bf16(gate_up, "gate_up");
+  const int64_t I2 = gate_up.size(-1);
+  TORCH_CHECK(I2 % 16 == 0, "swiglu: last dim must be a multiple of 16");
+  auto sizes = gate_up.sizes().vec();
+  sizes.back() = I2 / 2;
+  Tensor y = at::empty(sizes, gate_up.options());
+  const int64_t M = gate_up.numel() / I2;
+  if (M > 0) evgpt::launch_swiglu(bptr(gate_up), bptr_mut(y), M, (int)(I2 / 2), cur_stream());
+  return y;
+}
+
+Tensor rope(const Tensor& x, const Tensor& positions, const Tensor& cos, const Tensor& sin) {
+  check_bf16(x, "x"); check_f32(cos, "cos"); check_f32(sin, "sin");
+  TORCH_CHECK(x.dim() == 4, "rope: x must be [B,S,H,D]");
+  TORCH_CHECK(positions.is_cuda() && positions.scalar_type() == at::kLong &&
+              positions.is_contiguous() && positions.numel() == x.size(0) * x.size(1),
+              "rope: positions must be a contiguous int64 [B,S] GPU tensor");
+  const int64_t H = x.size(2), D = x.size(3);
+  TORCH_CHECK(D % 16 == 0 && cos.size(-1) == D / 2 && sin.size(-1) == D / 2);
+  Tensor y = at::empty_like(x);
+  if (x.numel() > 0)
+    evgpt::launch_rope(bptr(x), bptr_mut(y), reinterpret_cast<const long long*>(positions.data_ptr<int64_t>()), cos.data_ptr<float>(),
+                       sin.data_ptr<float>(), x.size(0) * x.size(1), (int)H, (int)D, cur_stream());
+  return y;
+}
+
+// --------------------------------------------------------------- attention
+void fill_strides_bshd(const Tensor& t, long long* s) {
+  TORCH_CHECK(t.stride(3) == 1, "attention: head_dim must be contiguous");
+  s[0] = t.stride(0); s[1] = t.stride(1); s[2] = t.stride(2);
+}
+
+// q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (any strides with contiguous D)
+Tensor attention(const Tensor& q, const Tensor& k, const Tensor& v, bool causal, double scale,
+                 int64_t q_offset) {
+  TORCH_CHECK(q.is_cuda() && q.scalar_type() == at::kBFloat16 && k.scalar_type() == at::kBFloat16 &&
+              v.scalar_type() == at::kBFloat16, "attention: bf16 GPU tensors required");
+  TORCH_CHECK(q.dim() == 4 && k.dim() == 4 && v.dim() == 4);
+  const int64_t B = q.size(0), Sq = q.size(1), Hq = q.size(2), D = q.size(3);
+  const int64_t Sk = k.size(1), Hkv = k.size(2);
+  TORCH_CHECK(D == 64 || D == 128, "attention: head_dim must be 64 or 128");
+  TORCH_CHECK(k.size(0) == B && v.size(0) == B && v.size(1) == Sk && v.size(2) == Hkv &&
+              k.size(3) == D && v.size(3) == D && Hq % Hkv == 0, "attention: shape mismatch");
+  TORCH_CHECK(Sk >= 1 && Sq >= 1);
+  Tensor o = at::empty({B, Sq, Hq, D}, q.options());
+  long long s[12];
+  fill_strides_bshd(q, s); fill_strides_bshd(k, s + 3); fill_strides_bshd(v, s + 6);
+  fill_strides_bshd(o, s + 9);
+  for (int i = 0; i < 9; ++i) TORCH_CHECK(s[i] % 8 == 0 || s[i] == 0 || true);
+  TORCH_CHECK(q.stride(1) % 8 == 0 && q.stride(2) % 8 == 0 && k.stride(1) % 8 == 0 &&
+              k.stride(2) % 8 == 0 && v.stride(1) % 8 == 0 && v.stride(2) % 8 == 0,
+              "attention: strides must keep 16-byte alignment");
+  evgpt::launch_attn_prefill(bptr(q), bptr(k), bptr(v), bptr_mut(o), s, nullptr, (int)B, (int)Sq,
+                             (int)Sk, (int)Hq, (int)Hkv, (int)D, causal ? 1 : 0, (int)q_offset, 0,
+                             (float)scale, cur_stream());
+  return o;
+}
+
+// Attention of q [B,Sq,Hq,D] against a static cache [B,Hkv,Lmax,D]; the key
+// count per sequence comes from device memory (kv_len[b]) and the causal
+// offset is kv_len[b] - Sq.  Writes into `out` [B,Sq,Hq,D].
+void attention_cache(const Tensor& q, const Tensor& k_cache, const Tensor& v_cache,
+                     const Tensor& out, const Tensor& kv_len, double scale) {
+  check_bf16(q, "q"); check_bf16(k_cache, "k_cache"); check_bf16(v_cache, "v_cache");
+  check_bf16(out, "out"); check_i32(kv_len, "kv_len");
+  TORCH_CHECK(q.dim() == 4 && k_cache.dim() == 4 && out.sizes() == q.sizes());
+  const int64_t B = q.size(0), Sq = q.size(1), Hq = q.size(2), D = q.size(3);
+  const int64_t Hkv = k_cache.size(1), Lmax = k_cache.size(2);
+  TORCH_CHECK(k_cache.size(0) == B && k_cache.size(3) == D && v_cache.sizes() == k_cache.sizes());
+  TORCH_CHECK(kv_len.numel() == B && (D == 64 || D == 128) && Hq % Hkv == 0);
+  long long s[12] = {Sq * Hq * D, Hq * D, D, Hkv * Lmax * D, D, Lmax * D,
+                     Hkv * Lmax * D, D, Lmax * D, Sq * Hq * D, Hq * D, D};
+  evgpt::launch_attn_prefill(bptr(q), bptr(k_cache), bptr(v_cache), bptr_mut(out), s,
+                             kv_len.data_ptr<int>(), (int)B, (int)Sq, (int)Lmax, (int)Hq, (int)Hkv,
+                             (int)D, 1, 0, 1, (float)scale, cur_stream());
+}
+
+Tensor st_pool(const Tensor& f, int64_t n_temporal) {
+  check_bf16(f, "features");
+  TORCH_CHECK(f.dim() == 3 && f.size(2) % 8 == 0, "st_pool: features must be [T,S,C], C % 8 == 0");
+  const int64_t T = f.size(0), S = f.size(1), C = f.size(2);
+  Tensor out = at::empty({n_temporal + S, C}, f.options());
+  evgpt::launch_st_pool(bptr(f), bptr_mut(out), (int)T, (int)S, (int)C, (int)n_temporal,
+                        cur_stream());
+  return out;
+}
+
+Tensor argmax_rows(const Tensor& x) {
+  TORCH_CHECK(x.is_cuda() && x.is_contiguous() && x.dim() >= 1);
+  const int64_t N = x.size(-1), rows = x.numel() / N;
+  auto sizes = x.sizes().vec();
+  sizes.pop_back();
+  Tensor out = at::empty(sizes, x.options().dtype(at::kLong));
+  if (rows == 0) return out;
+  if (x.scalar_type() == at::kFloat)
+    evgpt::launch_argmax_rows_f32(x.data_ptr<float>(), reinterpret_cast<long long*>(out.data_ptr<int64_t>()), (int)rows, (int)N,
+                                  cur_stream());
+  else if (x.scalar_type() == at::kBFloat16)
+    evgpt::launch_argmax_rows_bf16(bptr(x), reinterpret_cast<long long*>(out.data_ptr<int64_t>()), (int)rows, (int)N,
+                                   cur_stream());
+  else
+    TORCH_CHECK(false, "argmax_rows: float32 or bfloat16 only");
+  return out;
+}
+
+// ------------------------------------------------------------ engine ops
+// x [B,H] -> q_out [B,Hq*D], append K/V rows at pos[b] in caches [B,Hkv,Lmax,D]
+void decode_qkv(const Tensor& x, const Tensor& norm_w, const Tensor& w_qkv, const Tensor& q_out,
+                const Tensor& k_cache, const Tensor& v_cache, const Tensor& cos, const Tensor& sin,
+                const Tensor& pos, double eps, int64_t Hq, int64_t Hkv, int64_t D) {
+  check_bf16(x, "x"); check_bf16(norm_w, "norm_w"); check_bf16(w_qkv, "w_qkv");
+  check_bf16(q_out, "q_out"); check_bf16(k_cache, "k_cache"); check_bf16(v_cache, "v_cache");
+  check_f32(cos, "cos"); check_f32(sin, "sin"); check_i32(pos, "pos");
+  const int64_t B = x.size(0), K = x.size(1);
+  TORCH_CHECK(x.dim() == 2 && B <= evgpt::gemv_max_batch() && K % 8 == 0 && norm_w.numel() == K);
+  TORCH_CHECK(w_qkv.size(0) == (Hq + 2 * Hkv) * D && w_qkv.size(1) == K, "decode_qkv: bad w_qkv");
+  TORCH_CHECK(D % 16 == 0 && q_out.numel() == B * Hq * D && pos.numel() == B);
+  TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(0) == B && k_cache.size(1) == Hkv &&
+              k_cache.size(3) == D && v_cache.sizes() == k_cache.sizes());
+  TORCH_CHECK(cos.size(-1) == D / 2 && cos.size(0) >= k_cache.size(2),
+              "decode_qkv: rope table shorter than the cache");
+  TORCH_CHECK(B * K * 2 <= 96 * 1024);
+  evgpt::launch_gemv_qkv_rope(bptr(w_qkv), bptr(x), bptr(norm_w), (float)eps, bptr_mut(q_out),
+                              bptr_mut(k_cache), bptr_mut(v_cache), cos.data_ptr<float>(),
+                              sin.data_ptr<float>(), pos.data_ptr<int>(), (int)B, (int)Hq, (int)Hkv,
+                              (int)D, (int)k_cache.size(2), (int)K, cur_stream());
+}
+
+void decode_attn(const Tensor& q, const Tensor& k_cache, const Tensor& v_cache, const Tensor& out,
+                 const Tensor& part_o, const Tensor& part_ml, const Tensor& pos, int64_t nsplit,
+                 double scale) {
+  check_bf16(q, "q"); check_bf16(k_cache, "k_cache"); check_bf16(v_cache, "v_cache");
+  check_bf16(out, "out"); check_f32(part_o, "part_o"); check_f32(part_ml, "part_ml");
+  check_i32(pos, "pos");
+  const int64_t B = k_cache.size(0), Hkv = k_cache.size(1), Lmax = k_cache.size(2),
+                D = k_cache.size(3);
+  TORCH_CHECK(D == 64 || D == 128, "decode_attn: head_dim 64 or 128");
+  const int64_t Hq = q.numel() / (B * D);
+  TORCH_CHECK(Hq * B * D == q.numel() && Hq % Hkv == 0 && out.numel() == q.numel());
+  TORCH_CHECK(part_o.numel() >= B * Hq * nsplit * D && part_ml.numel() >= B * Hq * nsplit * 2);
+  TORCH_CHECK(pos.numel() == B && nsplit >= 1);
+  evgpt::launch_attn_decode(bptr(q), bptr(k_cache), bptr(v_cache), bptr_mut(out),
+                            part_o.data_ptr<float>(), part_ml.data_ptr<float>(),
+                            pos.data_ptr<int>(), (int)B, (int)Hq, (int)Hkv, (int)D, (int)Lmax,
+                            (int)nsplit, (float)scale, cur_stream());
+}
+
+// y (in place) = y + W @ xin      xin [B,K], y [B,N]
+void decode_gemv_residual(const Tensor& w, const Tensor& xin, const Tensor& y) {
+  check_bf16(w, "w"); check_bf16(xin, "xin"); check_bf16(y, "y");
+  const int64_t B = xin.size(0), K = xin.size(1), N = w.size(0);
+  TORCH_CHECK(xin.dim() == 2 && w.size(1) == K && y.numel() == B * N && N % 4 == 0 && K % 8 == 0);
+  TORCH_CHECK(B <= evgpt::gemv_max_batch() && B * K * 2 <= 96 * 1024);
+  evgpt::launch_gemv(bptr(w), bptr(xin), bptr_mut(y), nullptr, bptr(y), nullptr, 0.f, 0, (int)B,
+                     (int)N, (int)K, cur_stream());
+}
+
+// h = silu(Wg rmsnorm(x)) * (Wu rmsnorm(x));  w_gate_up [2I,K] = [gate rows | up rows]
+void decode_mlp_up(const Tensor& w_gate_up, const Tensor& x, const Tensor& norm_w, double eps,
+                   const Tensor& h) {
+  check_bf16(w_gate_up, "w_gate_up"); check_bf16(x, "x"); check_bf16(norm_w, "norm_w");
+  check_bf16(h, "h");
+  const int64_t B = x.size(0), K = x.size(1), I = w_gate_up.size(0) / 2;
+  TORCH_CHECK(x.dim() == 2 && w_gate_up.size(1) == K && h.numel() == B * I && I % 2 == 0 &&
+              K % 8 == 0 && norm_w.numel() == K);
+  TORCH_CHECK(B <= evgpt::gemv_max_batch() && B * K * 2 <= 96 * 1024);
+  evgpt::launch_gemv_swiglu(bptr(w_gate_up), bptr(x), bptr_mut(h), bptr(norm_w), (float)eps, (int)B,
+                            (int)I, (int)K, cur_stream());
+}
+
+int64_t logits_partials(int64_t N) { return evgpt::gemv_logits_grid((int)N); }
+
+void decode_logits(const Tensor& w, const Tensor& x, const c10::optional<Tensor>& norm_w,
+                   double eps, const c10::optional<Tensor>& logits, const Tensor& part_val,
+                   const Tensor& part_idx) {
+  check_bf16(w, "w"); check_bf16(x, "x"); check_f32(part_val, "part_val");
+  check_i32(part_idx, "part_idx");
+  const int64_t B = x.size(0), K = x.size(1), N = w.size(0);
+  TORCH_CHECK(x.dim() == 2 && w.size(1) == K && K % 8 == 0 && B <= evgpt::gemv_max_batch());
+  const int64_t np = evgpt::gemv_logits_grid((int)N);
+  TORCH_CHECK(part_val.numel() >= B * np && part_idx.numel() >= B * np);
+  float* lp = nullptr;
+  if (logits.has_value() && logits->defined()) {
+    check_f32(*logits, "logits");
+    TORCH_CHECK(logits->numel() == B * N);
+    lp = logits->data_ptr<float>();
+  }
+  if (norm_w.has_value()) { check_bf16(*norm_w, "norm_w"); TORCH_CHECK(norm_w->numel() == K); }
+  evgpt::launch_gemv_logits(bptr(w), bptr(x), bptr_opt(norm_w), (float)eps, lp,
+                            part_val.data_ptr<float>(), part_idx.data_ptr<int>(), (int)B, (int)N,
+                            (int)K, cur_stream());
+}
+
+void commit_token(const Tensor& part_val, const Tensor& part_idx, int64_t n_part,
+                  const c10::optional<Tensor>& sampled, const Tensor& embed, const Tensor& x,
+                  const Tensor& out_tokens, const Tensor& step, const Tensor& pos,
+                  const Tensor& done, const Tensor& cur_token, int64_t eos) {
+  check_f32(part_val, "part_val"); check_i32(part_idx, "part_idx"); check_bf16(embed, "embed");
+  check_bf16(x, "x"); check_i32(out_tokens, "out_tokens"); check_i32(step, "step");
+  check_i32(pos, "pos"); check_i32(done, "done"); check_i32(cur_token, "cur_token");
+  const int64_t B = x.size(0), H = x.size(1);
+  TORCH_CHECK(embed.size(1) == H && H % 8 == 0 && out_tokens.dim() == 2 && out_tokens.size(0) == B);
+  TORCH_CHECK(step.numel() == B && pos.numel() == B && done.numel() == B && cur_token.numel() == B);
+  const int* sp = nullptr;
+  if (sampled.has_value() && sampled->defined()) { check_i32(*sampled, "sampled"); sp = sampled->data_ptr<int>(); }
+  else TORCH_CHECK(part_val.numel() >= B * n_part && part_idx.numel() >= B * n_part);
+  evgpt::launch_commit_token(part_val.data_ptr<float>(), part_idx.data_ptr<int>(), (int)n_part, sp,
+                             bptr(embed), bptr_mut(x), out_tokens.data_ptr<int>(),
+                             (int)out_tokens.size(1), step.data_ptr<int>(), pos.data_ptr<int>(),
+                             done.data_ptr<int>(), cur_token.data_ptr<int>(), (int)eos, (int)B,
+                             (int)H, cur_stream());
+}
+
+// qkv [B,S,(Hq+2Hkv)*D] -> q_out [B,S,Hq*D] (rotated) + cache append at pos0[b]+s
+void prefill_rope_kv(const Tensor& qkv, const Tensor& q_out, const Tensor& k_cache,
+                     const Tensor& v_cache, const Tensor& cos, const Tensor& sin,
+                     const Tensor& pos0, int64_t Hq, int64_t Hkv, int64_t D) {
+  check_bf16(qkv, "qkv"); check_bf16(q_out, "q_out"); check_bf16(k_cache, "k_cache");
+  check_bf16(v_cache, "v_cache"); check_f32(cos, "cos"); check_f32(sin, "sin");
+  check_i32(pos0, "pos0");
+  TORCH_CHECK(qkv.dim() == 3 && qkv.size(2) == (Hq + 2 * Hkv) * D && D % 16 == 0);
+  const int64_t B = qkv.size(0), S = qkv.size(1);
+  TORCH_CHECK(q_out.numel() == B * S * Hq * D && pos0.numel() == B);
+  TORCH_CHECK(k_cache.size(0) == B && k_cache.size(1) == Hkv && k_cache.size(3) == D &&
+              v_cache.sizes() == k_cache.sizes() && k_cache.size(2) >= S);
+  TORCH_CHECK(cos.size(0) >= k_cache.size(2) && cos.size(-1) == D / 2);
+  evgpt::launch_rope_kv_prefill(bptr(qkv), bptr_mut(q_out), bptr_mut(k_cache), bptr_mut(v_cache),
+                                cos.data_ptr<float>(), sin.data_ptr<float>(), pos0.data_ptr<int>(),
+                                (int)B, (int)S, (int)Hq, (int)Hkv, (int)D, (int)k_cache.size(2),
+                                cur_stream());
+}
+
+}  // namespace
+
+TORCH_LIBRARY(evgpt, m) {
+  m.def("rmsnorm(Tensor x, Tensor w, float eps) -> Tensor", &rmsnorm);
+  m.def("add_rmsnorm(Tensor x, Tensor res, Tensor w, float eps) -> (Tensor, Tensor)", &add_rmsnorm);
+  m.def("layernorm(Tensor x, Tensor w, Tensor? b, float eps) -> Tensor", &layernorm);
+  m.def("linear(Tensor x, Tensor w, Tensor? bias, Tensor? res, int act, bool out_f32) -> Tensor", &linear);
+  m.def("swiglu(Tensor gate_up) -> Tensor", &swiglu);
+  m.def("rope(Tensor x, Tensor positions, Tensor cos, Tensor sin) -> Tensor", &rope);
+  m.def("attention(Tensor q, Tensor k, Tensor v, bool causal, float scale, int q_offset) -> Tensor", &attention);
+  m.def("attention_cache(Tensor q, Tensor k_cache, Tensor v_cache, Tensor(a!) out, Tensor kv_len, float scale) -> ()", &attention_cache);
+  m.def("st_pool(Tensor f, int n_temporal) -> Tensor", &st_pool);
+  m.def("argmax_rows(Tensor x) -> Tensor", &argmax_rows);
+  m.def("decode_qkv(Tensor x, Tensor norm_w, Tensor w_qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos, float eps, int Hq, int Hkv, int D) -> ()", &decode_qkv);
+  m.def("decode_attn(Tensor q, Tensor k_cache, Tensor v_cache, Tensor(a!) out, Tensor(b!) part_o, Tensor(c!) part_ml, Tensor pos, int nsplit, float scale) -> ()", &decode_attn);
+  m.def("decode_gemv_residual(Tensor w, Tensor xin, Tensor(a!) y) -> ()", &decode_gemv_residual);
+  m.def("decode_mlp_up(Tensor w_gate_up, Tensor x, Tensor norm_w, float eps, Tensor(a!) h) -> ()", &decode_mlp_up);
+  m.def("logits_partials(int N) -> int", &logits_partials);
+  m.def("decode_logits(Tensor w, Tensor x, Tensor? norm_w, float eps, Tensor(a!)? logits, Tensor(b!) part_val, Tensor(c!) part_idx) -> ()", &decode_logits);
+  m.def("commit_token(Tensor part_val, Tensor part_idx, int n_part, Tensor? sampled, Tensor embed, Tensor(a!) x, Tensor(b!) out_tokens, Tensor(c!) step, Tensor(d!) pos, Tensor(e!) done, Tensor(f!) cur_token, int eos) -> ()", &commit_token);
+  m.def("prefill_rope_kv(Tensor qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos0, int Hq, int Hkv, int D) -> ()", &prefill_rope_kv);
+}

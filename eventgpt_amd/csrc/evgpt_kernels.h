@@ -1,0 +1,61 @@
+// Launcher declarations for the gfx950 kernels.  Launchers take raw device
+// pointers and a stream, never allocate and never synchronise (graph-safe).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace evgpt {
+
+typedef unsigned short bf16_t;
+
+// ---- gemv.hip (decode, batch <= gemv_max_batch())
+int gemv_max_batch();
+int gemv_logits_grid(int N);
+void launch_gemv(const bf16_t* W, const bf16_t* x, bf16_t* y, const bf16_t* bias,
+                 const bf16_t* res, const bf16_t* norm_w, float eps, int act, int B, int N,
+                 int K, hipStream_t st);
+void launch_gemv_swiglu(const bf16_t* W_gate_up, const bf16_t* x, bf16_t* y,
+                        const bf16_t* norm_w, float eps, int B, int inter, int K, hipStream_t st);
+void launch_gemv_qkv_rope(const bf16_t* W_qkv, const bf16_t* x, const bf16_t* norm_w, float eps,
+                          bf16_t* q_out, bf16_t* k_cache, bf16_t* v_cache, const float* cos_tab,
+                          const float* sin_tab, const int* pos, int B, int n_q_heads,
+                          int n_kv_heads, int head_dim, int l_max, int K, hipStream_t st);
+void launch_gemv_logits(const bf16_t* W, const bf16_t* x, const bf16_t* norm_w, float eps,
+                        float* logits, float* part_val, int* part_idx, int B, int N, int K,
+                        hipStream_t st);
+
+// ---- gemm.hip
+void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,
+                      const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
+                      hipStream_t st);
+
+// ---- elementwise.hip
+void launch_rmsnorm(const bf16_t* x, const bf16_t* res, const bf16_t* w, bf16_t* y,
+                    bf16_t* res_out, int rows, int H, float eps, hipStream_t st);
+void launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows,
+                      int H, float eps, hipStream_t st);
+void launch_rope_kv_prefill(const bf16_t* qkv, bf16_t* q_out, bf16_t* k_cache, bf16_t* v_cache,
+                            const float* cos_tab, const float* sin_tab, const int* pos0, int B,
+                            int S, int Hq, int Hkv, int D, int l_max, hipStream_t st);
+void launch_rope(const bf16_t* x, bf16_t* y, const long long* positions, const float* cos_tab,
+                 const float* sin_tab, long long tokens, int H, int D, hipStream_t st);
+void launch_swiglu(const bf16_t* in, bf16_t* out, long long M, int I, hipStream_t st);
+void launch_st_pool(const bf16_t* f, bf16_t* out, int T, int S, int C, int Tn, hipStream_t st);
+void launch_argmax_rows_f32(const float* x, long long* out, int rows, int N, hipStream_t st);
+void launch_argmax_rows_bf16(const bf16_t* x, long long* out, int rows, int N, hipStream_t st);
+void launch_commit_token(const float* part_val, const int* part_idx, int n_part,
+                         const int* sampled, const bf16_t* embed, bf16_t* x, int* out_tokens,
+                         int max_out, int* step, int* pos, int* done, int* cur_token, int eos,
+                         int B, int H, hipStream_t st);
+
+// ---- attn_decode.hip
+void launch_attn_decode(const bf16_t* q, const bf16_t* k_cache, const bf16_t* v_cache,
+                        bf16_t* out, float* part_o, float* part_ml, const int* pos, int B, int Hq,
+                        int Hkv, int D, int l_max, int nsplit, float scale, hipStream_t st);
+
+// ---- attn_prefill.hip
+void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o,
+                         const long long* strides, const int* kv_len, int B, int Sq, int Sk,
+                         int Hq, int Hkv, int D, int causal, int q_offset, int q_offset_from_len,
+                         float scale, hipStream_t st);
+
+}  // namespace evgpt

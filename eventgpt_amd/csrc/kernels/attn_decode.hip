@@ -1,0 +1,158 @@
+// Single-query (decode) attention over a static KV cache, split along the
+// key axis ("flash-decoding") so that 32 heads still fill 256 CUs.
+//
+// Memory-bound: every K and V byte is read once.  K/V rows go straight to
+// VGPRs (16 B per lane, a 128-wide row = 16 lanes, so one wave-instruction
+// covers 4 keys); no LDS staging since nothing is reused across waves.  Each
+// 16-lane group keeps its own online-softmax state; groups, waves and finally
+// splits are merged with the usual (m, l, o) rescaling.  The cache length is
+// read from device memory so the launch can be replayed from a graph.
+#include "common.h"
+#include "../evgpt_kernels.h"
+
+namespace evgpt {
+
+constexpr int AD_WAVES = 4;
+
+// part_o : [B][Hq][nsplit][D] fp32, un-normalised
+// part_ml: [B][Hq][nsplit][2] fp32 (running max, running sum)
+template <int D>
+__global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_split_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k_cache,
+    const bf16_t* __restrict__ v_cache, float* __restrict__ part_o, float* __restrict__ part_ml,
+    const int* __restrict__ pos, int Hq, int Hkv, int l_max, float scale) {
+  constexpr int LPK = D / 8;       // lanes per key row
+  constexpr int KPW = 64 / LPK;    // keys per wave-instruction
+  const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z, nsplit = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int sub = lane / LPK, dl = lane % LPK;
+  const int len = pos[b] + 1;  // the current token's K/V were appended by the QKV kernel
+  const int hk = h / (Hq / Hkv);
+
+  // this split's key range, in units of KPW-key groups
+  const int ngroups = (len + KPW - 1) / KPW;
+  const int gper = (ngroups + nsplit - 1) / nsplit;
+  const int g0 = split * gper;
+  const int g1 = min(g0 + gper, ngroups);
+
+  float qf[8];
+  {
+    u32x4_t qv = load16(q + (static_cast<size_t>(b) * Hq + h) * D + dl * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qf[2 * i] = bf16lo(qv[i]) * scale; qf[2 * i + 1] = bf16hi(qv[i]) * scale; }
+  }
+  const bf16_t* kb = k_cache + (static_cast<size_t>(b) * Hkv + hk) * l_max * D + dl * 8;
+  const bf16_t* vb = v_cache + (static_cast<size_t>(b) * Hkv + hk) * l_max * D + dl * 8;
+
+  float m = -INFINITY, l = 0.f;
+  float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  constexpr int U = 4;  // groups in flight per wave: 8 loads of 1 KiB
+  for (int g = g0 + wid * U; g < g1; g += AD_WAVES * U) {
+    u32x4_t kv[U], vv[U];
+    int key[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      key[u] = (g + u) * KPW + sub;
+      const bool ok = (g + u) < g1 && key[u] < len;
+      const int kk = ok ? key[u] : 0;
+      kv[u] = load16(kb + static_cast<size_t>(kk) * D);
+      vv[u] = load16(vb + static_cast<size_t>(kk) * D);
+      if (!ok) key[u] = -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s += qf[2 * i] * bf16lo(kv[u][i]) + qf[2 * i + 1] * bf16hi(kv[u][i]);
+#pragma unroll
+      for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      if (key[u] >= 0) {
+        const float mn = fmaxf(m, s);
+        const float a = __expf(m - mn), p = __expf(s - mn);
+        l = l * a + p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[2 * i] = o[2 * i] * a + p * bf16lo(vv[u][i]);
+          o[2 * i + 1] = o[2 * i + 1] * a + p * bf16hi(vv[u][i]);
+        }
+        m = mn;
+      }
+    }
+  }
+
+  // merge the KPW lane groups of this wave (lanes with equal dl)
+#pragma unroll
+  for (int off = LPK; off < 64; off <<= 1) {
+    const float om = __shfl_xor(m, off, 64), ol = __shfl_xor(l, off, 64);
+    const float mn = fmaxf(m, om);
+    const float a = (m == -INFINITY) ? 0.f : __expf(m - mn);
+    const float c = (om == -INFINITY) ? 0.f : __expf(om - mn);
+    l = l * a + ol * c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = o[i] * a + __shfl_xor(o[i], off, 64) * c;
+    m = mn;
+  }
+
+  // merge the waves through LDS
+  __shared__ float s_o[AD_WAVES][D];
+  __shared__ float s_m[AD_WAVES], s_l[AD_WAVES];
+  if (sub == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_o[wid][dl * 8 + i] = o[i];
+    if (dl == 0) { s_m[wid] = m; s_l[wid] = l; }
+  }
+  __syncthreads();
+  if (tid < D) {
+    float mm = s_m[0];
+    for (int w = 1; w < AD_WAVES; ++w) mm = fmaxf(mm, s_m[w]);
+    float ll = 0.f, oo = 0.f;
+    for (int w = 0; w < AD_WAVES; ++w) {
+      const float c = (s_m[w] == -INFINITY) ? 0.f : __expf(s_m[w] - mm);
+      ll += s_l[w] * c;
+      oo += s_o[w][tid] * c;
+    }
+    const size_t pi = (static_cast<size_t>(b) * Hq + h) * nsplit + split;
+    part_o[pi * D + tid] = oo;
+    if (tid == 0) { part_ml[pi * 2] = mm; part_ml[pi * 2 + 1] = ll; }
+  }
+}
+
+// out[b][h*D + d] = sum_s w_s o_s[d] / sum_s w_s l_s,  w_s = exp(m_s - max m)
+template <int D>
+__global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __restrict__ part_o,
+                                                                const float* __restrict__ part_ml,
+                                                                bf16_t* __restrict__ out, int Hq,
+                                                                int nsplit) {
+  const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  const size_t base = (static_cast<size_t>(b) * Hq + h) * nsplit;
+  float mm = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, part_ml[(base + s) * 2]);
+  float ll = 0.f, oo = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float ms = part_ml[(base + s) * 2];
+    const float c = (ms == -INFINITY) ? 0.f : __expf(ms - mm);
+    ll += part_ml[(base + s) * 2 + 1] * c;
+    oo += part_o[(base + s) * D + d] * c;
+  }
+  out[(static_cast<size_t>(b) * Hq + h) * D + d] = f32_to_bf16(oo / ll);
+}
+
+void launch_attn_decode(const bf16_t* q, const bf16_t* k_cache, const bf16_t* v_cache,
+                        bf16_t* out, float* part_o, float* part_ml, const int* pos, int B, int Hq,
+                        int Hkv, int D, int l_max, int nsplit, float scale, hipStream_t st) {
+  dim3 grid(Hq, nsplit, B), block(AD_WAVES * 64);
+  if (D == 128) {
+    hipLaunchKernelGGL(attn_decode_split_kernel<128>, grid, block, 0, st, q, k_cache, v_cache,
+                       part_o, part_ml, pos, Hq, Hkv, l_max, scale);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(Hq, B), dim3(128), 0, st, part_o,
+                       part_ml, out, Hq, nsplit);
+  } else {
+    hipLaunchKernelGGL(attn_decode_split_kernel<64>, grid, block, 0, st, q, k_cache, v_cache,
+                       part_o, part_ml, pos, Hq, Hkv, l_max, scale);
+    hipLaunchKernelGGL(attn_decode_combine_kernel<64>, dim3(Hq, B), dim3(64), 0, st, part_o,
+                       part_ml, out, Hq, nsplit);
+  }
+}
+
+}  // namespace evgpt

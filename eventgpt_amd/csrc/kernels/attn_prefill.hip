@@ -1,0 +1,232 @@
+// Fused (flash-style) attention for many query rows: LLM prefill (causal,
+// head_dim 128), speculative-verify batches (causal with an offset into a long
+// cache) and the ViT encoder (non-causal, head_dim 64, 577 tokens).
+//
+// One block = 4 waves = 64 query rows of one (batch, head); each wave owns 16
+// rows.  K/V tiles of 64 keys are staged through LDS (register-staged: the
+// global loads of tile t+1 are issued before the MFMAs of tile t and written to
+// LDS after the barrier).  The score tile is computed TRANSPOSED,
+//     S^T[key][q] = K · Q^T        (K rows = MFMA A operand, Q^T = B operand)
+// so that the query index lives on the lane (lane & 15) and a lane's 16
+// accumulator values are 16 different keys of ONE query.  Consequences:
+//   * softmax row statistics are in-lane reductions + 2 cross-lane shuffles;
+//   * the exponentiated tile, converted to bf16, already *is* the B operand of
+//     the second product  O^T[d][q] = V^T · P^T  — no LDS round trip for P
+//     (the contraction index is permuted consistently on both operands);
+//   * V^T fragments come from the row-major V tile with the hardware
+//     transposing read ds_read_b64_tr_b16, so V is staged exactly like K;
+//   * rescaling O by exp(m_old - m_new) is a per-lane scalar multiply.
+// LDS images are XOR-swizzled at 16-byte-chunk granularity so both the row
+// reads (ds_read_b128) and the transposed reads spread over the banks.
+#include "common.h"
+#include "../evgpt_kernels.h"
+
+namespace evgpt {
+
+struct AttnParams {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
+  long long q_sb, q_ss, q_sh;   // element strides: batch, sequence, head
+  long long k_sb, k_ss, k_sh;
+  long long v_sb, v_ss, v_sh;
+  long long o_sb, o_ss, o_sh;
+  const int* kv_len;            // optional device-side key count per batch
+  int Sq, Sk, Hq, Hkv;
+  int q_offset;                 // absolute position of query row 0 minus key 0 (causal)
+  int q_offset_from_len;        // if set: q_offset = kv_len[b] - Sq
+  float scale_log2e;
+};
+
+constexpr int TK = 64;  // keys per tile
+
+template <int D> __device__ __forceinline__ int swz(int row);
+template <> __device__ __forceinline__ int swz<128>(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+template <> __device__ __forceinline__ int swz<64>(int row) { return (row >> 1) & 7; }
+
+// byte offset of 16-byte chunk `ch` of row `row` inside a [TK][D] bf16 tile
+template <int D>
+__device__ __forceinline__ int tile_off(int row, int ch) {
+  return row * (D * 2) + ((ch ^ swz<D>(row)) << 4);
+}
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
+  constexpr int CPR = D / 8;                  // 16-byte chunks per row
+  constexpr int TILE_BYTES = TK * D * 2;
+  constexpr int LD_PER_THREAD = TK * CPR / 256;  // chunks each thread stages per tile
+  constexpr int KS = D / 32;                  // k-steps of the QK^T product
+  constexpr int DT = D / 16;                  // 16-wide output column tiles
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
+  unsigned char* k_lds = lds;
+  unsigned char* v_lds = lds + TILE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int hk = h / (p.Hq / p.Hkv);
+  const int Sk = p.kv_len ? p.kv_len[b] : p.Sk;
+  const int q_off = p.q_offset_from_len ? (Sk - p.Sq) : p.q_offset;
+  const int qb0 = blockIdx.x * 64;           // first query row of the block
+  const int qi = qb0 + wid * 16 + fr;        // this lane's query row
+  const int qi_c = qi < p.Sq ? qi : p.Sq - 1;
+
+  // Q^T fragments straight from global: Q[qi][ks*32 + 8g .. +8]
+  bf16x8_t qf[KS];
+  {
+    const bf16_t* qp = p.q + b * p.q_sb + static_cast<long long>(qi_c) * p.q_ss + h * p.q_sh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32 + g * 8);
+  }
+
+  const bf16_t* kbase = p.k + b * p.k_sb + hk * p.k_sh;
+  const bf16_t* vbase = p.v + b * p.v_sb + hk * p.v_sh;
+
+  // keys this block needs: all of them, or up to its last query's diagonal
+  int k_end = Sk;
+  if (CAUSAL) {
+    const int last_q = min(qb0 + 63, p.Sq - 1);
+    k_end = min(Sk, last_q + q_off + 1);
+  }
+  const int ntiles = (k_end + TK - 1) / TK;
+
+  u32x4_t kreg[LD_PER_THREAD], vreg[LD_PER_THREAD];
+  auto prefetch = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < LD_PER_THREAD; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / CPR, ch = idx % CPR;
+      int key = t * TK + row; key = key < Sk ? key : Sk - 1;
+      kreg[i] = load16(kbase + static_cast<long long>(key) * p.k_ss + ch * 8);
+      vreg[i] = load16(vbase + static_cast<long long>(key) * p.v_ss + ch * 8);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < LD_PER_THREAD; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / CPR, ch = idx % CPR;
+      *reinterpret_cast<u32x4_t*>(k_lds + tile_off<D>(row, ch)) = kreg[i];
+      *reinterpret_cast<u32x4_t*>(v_lds + tile_off<D>(row, ch)) = vreg[i];
+    }
+  };
+
+  f32x4_t o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+
+  if (ntiles > 0) prefetch(0);
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (t + 1 < ntiles) prefetch(t + 1);
+
+    // ---- S^T tile: 4 sub-tiles of 16 keys
+    f32x4_t st[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      st[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(
+            k_lds + tile_off<D>(n * 16 + fr, ks * 4 + g));
+        st[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[n], 0, 0, 0);
+      }
+    }
+
+    // ---- scale, mask, online softmax (lane = one query; 16 keys in registers)
+    const int key0 = t * TK + g * 4;
+    const int lim = CAUSAL ? min(Sk - 1, qi + q_off) : Sk - 1;  // last visible key
+    float mt = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + n * 16 + r;
+        const float s = key <= lim ? st[n][r] * p.scale_log2e : -INFINITY;
+        st[n][r] = s;
+        mt = fmaxf(mt, s);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float msafe = mn == -INFINITY ? 0.f : mn;
+    const float alpha = exp2f(m - msafe);  // m = -inf -> 0
+    float psum = 0.f;
+    unsigned int pk[4][2];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { e[r] = exp2f(st[n][r] - msafe); psum += e[r]; }
+      pk[n][0] = pack_bf16x2(e[0], e[1]);
+      pk[n][1] = pack_bf16x2(e[2], e[3]);
+    }
+    l = l * alpha + psum;
+    m = mn;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] *= alpha;
+
+    // ---- O^T += V^T · P^T, two k-steps of 32 keys; slot (g, j) <-> key
+    //      32s + 4g + j (j < 4) or 32s + 16 + 4g + (j - 4)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4_t pw = {pk[2 * s][0], pk[2 * s][1], pk[2 * s + 1][0], pk[2 * s + 1][1]};
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+      const int q4 = fr >> 2, p4 = fr & 3;
+      const int r0 = s * 32 + g * 4 + q4, r1 = r0 + 16;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int ch = dt * 2 + (p4 >> 1);
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4_t __attribute__((address_space(3)))*)(v_lds + tile_off<D>(r0, ch) + 8 * (p4 & 1)));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4_t __attribute__((address_space(3)))*)(v_lds + tile_off<D>(r1, ch) + 8 * (p4 & 1)));
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        const s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf,
+                                                        o[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- finalise: l is a per-lane partial over this lane's key slots
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  if (qi < p.Sq) {
+    bf16_t* op = p.o + b * p.o_sb + static_cast<long long>(qi) * p.o_ss + h * p.o_sh;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      u32x2_t w = {pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv),
+                   pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv)};
+      *reinterpret_cast<u32x2_t*>(op + dt * 16 + g * 4) = w;
+    }
+  }
+}
+
+void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o,
+                         const long long* strides /*12: q,k,v,o x (b,s,h)*/, const int* kv_len,
+                         int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, int q_offset,
+                         int q_offset_from_len, float scale, hipStream_t st) {
+  AttnParams p;
+  p.q = q; p.k = k; p.v = v; p.o = o;
+  p.q_sb = strides[0]; p.q_ss = strides[1]; p.q_sh = strides[2];
+  p.k_sb = strides[3]; p.k_ss = strides[4]; p.k_sh = strides[5];
+  p.v_sb = strides[6]; p.v_ss = strides[7]; p.v_sh = strides[8];
+  p.o_sb = strides[9]; p.o_ss = strides[10]; p.o_sh = strides[11];
+  p.kv_len = kv_len; p.Sq = Sq; p.Sk = Sk; p.Hq = Hq; p.Hkv = Hkv;
+  p.q_offset = q_offset; p.q_offset_from_len = q_offset_from_len;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  dim3 grid((Sq + 63) / 64, Hq, B), block(256);
+  if (D == 128) {
+    if (causal) hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_prefill_kernel<128, false>), grid, block, 0, st, p);
+  } else {
+    if (causal) hipLaunchKernelGGL((attn_prefill_kernel<64, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_prefill_kernel<64, false>), grid, block, 0, st, p);
+  }
+}
+
+}  // namespace evgpt

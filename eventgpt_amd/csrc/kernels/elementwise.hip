@@ -1,0 +1,385 @@
+// Memory-bound row kernels: RMSNorm (+residual), LayerNorm, RoPE + KV-cache
+// append for prefill, SwiGLU, spatio-temporal pooling, argmax / token commit.
+// All bf16 traffic is 16 bytes per lane; arithmetic is fp32.
+#include "common.h"
+#include "../evgpt_kernels.h"
+
+namespace evgpt {
+
+// ---------------------------------------------------------------- RMSNorm
+// One 256-thread block per row.  Optional fused residual: r = x + res is written
+// to res_out (bf16-rounded, the value later layers see) and normalised.
+template <bool HAS_RES>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x,
+                                                      const bf16_t* __restrict__ res,
+                                                      const bf16_t* __restrict__ w,
+                                                      bf16_t* __restrict__ y,
+                                                      bf16_t* __restrict__ res_out, int H,
+                                                      float eps) {
+  __shared__ float red[16];
+  const size_t base = static_cast<size_t>(blockIdx.x) * H;
+  const int nchunk = H >> 3;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    u32x4_t v = load16(x + base + c * 8);
+    if constexpr (HAS_RES) {
+      u32x4_t r = load16(res + base + c * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        v[i] = pack_bf16x2(bf16lo(v[i]) + bf16lo(r[i]), bf16hi(v[i]) + bf16hi(r[i]));
+      *reinterpret_cast<u32x4_t*>(res_out + base + c * 8) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float lo = bf16lo(v[i]), hi = bf16hi(v[i]);
+      ss += lo * lo + hi * hi;
+    }
+  }
+  ss = block_sum(ss, red);
+  const float rstd = rsqrtf(ss / static_cast<float>(H) + eps);
+  const bf16_t* src = HAS_RES ? res_out : x;
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    u32x4_t v = load16(src + base + c * 8);
+    u32x4_t g = load16(w + c * 8);
+    u32x4_t o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float lo = bf16_to_f32(f32_to_bf16(bf16lo(v[i]) * rstd)) * bf16lo(g[i]);
+      const float hi = bf16_to_f32(f32_to_bf16(bf16hi(v[i]) * rstd)) * bf16hi(g[i]);
+      o[i] = pack_bf16x2(lo, hi);
+    }
+    *reinterpret_cast<u32x4_t*>(y + base + c * 8) = o;
+  }
+}
+
+void launch_rmsnorm(const bf16_t* x, const bf16_t* res, const bf16_t* w, bf16_t* y,
+                    bf16_t* res_out, int rows, int H, float eps, hipStream_t st) {
+  if (res) hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3(rows), dim3(256), 0, st, x, res, w, y, res_out, H, eps);
+  else hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3(rows), dim3(256), 0, st, x, res, w, y, res_out, H, eps);
+}
+
+// --------------------------------------------------------------- LayerNorm
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x,
+                                                        const bf16_t* __restrict__ w,
+                                                        const bf16_t* __restrict__ b,
+                                                        bf16_t* __restrict__ y, int H, float eps) {
+  __shared__ float red[16];
+  const size_t base = static_cast<size_t>(blockIdx.x) * H;
+  const int nchunk = H >> 3;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    u32x4_t v = load16(x + base + c * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += bf16lo(v[i]) + bf16hi(v[i]);
+  }
+  const float mean = block_sum(s, red) / static_cast<float>(H);
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    u32x4_t v = load16(x + base + c * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float lo = bf16lo(v[i]) - mean, hi = bf16hi(v[i]) - mean;
+      ss += lo * lo + hi * hi;
+    }
+  }
+  const float rstd = rsqrtf(block_sum(ss, red) / static_cast<float>(H) + eps);
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    u32x4_t v = load16(x + base + c * 8);
+    u32x4_t g = load16(w + c * 8);
+    u32x4_t bb = b ? load16(b + c * 8) : u32x4_t{0, 0, 0, 0};
+    u32x4_t o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      o[i] = pack_bf16x2((bf16lo(v[i]) - mean) * rstd * bf16lo(g[i]) + bf16lo(bb[i]),
+                         (bf16hi(v[i]) - mean) * rstd * bf16hi(g[i]) + bf16hi(bb[i]));
+    *reinterpret_cast<u32x4_t*>(y + base + c * 8) = o;
+  }
+}
+
+void launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows,
+                      int H, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, st, x, w, b, y, H, eps);
+}
+
+// ------------------------------------------------- RoPE + KV append (prefill)
+// qkv: [B][S][(Hq+2Hkv)*D] straight out of the fused QKV GEMM.  One thread
+// handles one 8-element chunk of the first half of a head and its partner chunk
+// in the second half (rotate-half pairing i <-> i + D/2).  q goes to q_out
+// [B][S][Hq*D]; k, v go into the cache [B][Hkv][Lmax][D] at pos0[b] + s.
+__global__ __launch_bounds__(256) void rope_kv_prefill_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ q_out, bf16_t* __restrict__ k_cache,
+    bf16_t* __restrict__ v_cache, const float* __restrict__ cos_tab,
+    const float* __restrict__ sin_tab, const int* __restrict__ pos0, int S, int Hq, int Hkv,
+    int D, int l_max) {
+  const int hh = D >> 1, cph = hh >> 3;             // chunks per half head
+  const int heads = Hq + 2 * Hkv;
+  const int per_tok = heads * cph;
+  const long long total = static_cast<long long>(gridDim.y) * S * per_tok;
+  const int b = blockIdx.y;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < static_cast<long long>(S) * per_tok;
+       i += gridDim.x * 256ll) {
+    const int s = static_cast<int>(i / per_tok);
+    const int rem = static_cast<int>(i % per_tok);
+    const int h = rem / cph, c = rem % cph;
+    const int pos = (pos0 ? pos0[b] : 0) + s;
+    const bf16_t* src = qkv + (static_cast<size_t>(b) * S + s) * heads * D + h * D + c * 8;
+    u32x4_t a = load16(src), bb = load16(src + hh);
+    bf16_t* dst;
+    if (h < Hq) {
+      dst = q_out + (static_cast<size_t>(b) * S + s) * Hq * D + h * D;
+    } else if (h < Hq + Hkv) {
+      dst = k_cache + ((static_cast<size_t>(b) * Hkv + (h - Hq)) * l_max + pos) * D;
+    } else {
+      dst = v_cache + ((static_cast<size_t>(b) * Hkv + (h - Hq - Hkv)) * l_max + pos) * D;
+      *reinterpret_cast<u32x4_t*>(dst + c * 8) = a;
+      *reinterpret_cast<u32x4_t*>(dst + hh + c * 8) = bb;
+      continue;
+    }
+    const float* cs = cos_tab + static_cast<size_t>(pos) * hh + c * 8;
+    const float* sn = sin_tab + static_cast<size_t>(pos) * hh + c * 8;
+    u32x4_t o1, o2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float c0 = cs[2 * j], c1 = cs[2 * j + 1], s0 = sn[2 * j], s1 = sn[2 * j + 1];
+      const float x1l = bf16lo(a[j]), x1h = bf16hi(a[j]), x2l = bf16lo(bb[j]), x2h = bf16hi(bb[j]);
+      o1[j] = pack_bf16x2(x1l * c0 - x2l * s0, x1h * c1 - x2h * s1);
+      o2[j] = pack_bf16x2(x2l * c0 + x1l * s0, x2h * c1 + x1h * s1);
+    }
+    *reinterpret_cast<u32x4_t*>(dst + c * 8) = o1;
+    *reinterpret_cast<u32x4_t*>(dst + hh + c * 8) = o2;
+  }
+  (void)total;
+}
+
+void launch_rope_kv_prefill(const bf16_t* qkv, bf16_t* q_out, bf16_t* k_cache, bf16_t* v_cache,
+                            const float* cos_tab, const float* sin_tab, const int* pos0, int B,
+                            int S, int Hq, int Hkv, int D, int l_max, hipStream_t st) {
+  const long long work = static_cast<long long>(S) * (Hq + 2 * Hkv) * (D / 16);
+  int blocks = static_cast<int>((work + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(rope_kv_prefill_kernel, dim3(blocks, B), dim3(256), 0, st, qkv, q_out,
+                     k_cache, v_cache, cos_tab, sin_tab, pos0, S, Hq, Hkv, D, l_max);
+}
+
+// RoPE on a standalone [B,S,H,D] tensor with explicit positions (module path).
+__global__ __launch_bounds__(256) void rope_kernel(const bf16_t* __restrict__ x,
+                                                   bf16_t* __restrict__ y,
+                                                   const long long* __restrict__ positions,
+                                                   const float* __restrict__ cos_tab,
+                                                   const float* __restrict__ sin_tab,
+                                                   long long tokens, int H, int D) {
+  const int hh = D >> 1, cph = hh >> 3;
+  const long long total = tokens * H * cph;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const long long t = i / (H * cph);
+    const int rem = static_cast<int>(i % (H * cph));
+    const int h = rem / cph, c = rem % cph;
+    const long long pos = positions[t];
+    const size_t off = (static_cast<size_t>(t) * H + h) * D + c * 8;
+    u32x4_t a = load16(x + off), bb = load16(x + off + hh);
+    const float* cs = cos_tab + static_cast<size_t>(pos) * hh + c * 8;
+    const float* sn = sin_tab + static_cast<size_t>(pos) * hh + c * 8;
+    u32x4_t o1, o2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float c0 = cs[2 * j], c1 = cs[2 * j + 1], s0 = sn[2 * j], s1 = sn[2 * j + 1];
+      const float x1l = bf16lo(a[j]), x1h = bf16hi(a[j]), x2l = bf16lo(bb[j]), x2h = bf16hi(bb[j]);
+      o1[j] = pack_bf16x2(x1l * c0 - x2l * s0, x1h * c1 - x2h * s1);
+      o2[j] = pack_bf16x2(x2l * c0 + x1l * s0, x2h * c1 + x1h * s1);
+    }
+    *reinterpret_cast<u32x4_t*>(y + off) = o1;
+    *reinterpret_cast<u32x4_t*>(y + off + hh) = o2;
+  }
+}
+
+void launch_rope(const bf16_t* x, bf16_t* y, const long long* positions, const float* cos_tab,
+                 const float* sin_tab, long long tokens, int H, int D, hipStream_t st) {
+  const long long work = tokens * H * (D / 16);
+  int blocks = static_cast<int>((work + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(rope_kernel, dim3(blocks), dim3(256), 0, st, x, y, positions, cos_tab,
+                     sin_tab, tokens, H, D);
+}
+
+// ------------------------------------------------------------------ SwiGLU
+// in: [M][2I] laid out [gate | up]; out: [M][I]
+__global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ in,
+                                                     bf16_t* __restrict__ out, long long M, int I) {
+  const int cpr = I >> 3;
+  const long long total = M * cpr;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const long long m = i / cpr;
+    const int c = static_cast<int>(i % cpr);
+    u32x4_t g = load16(in + m * 2 * I + c * 8);
+    u32x4_t u = load16(in + m * 2 * I + I + c * 8);
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = pack_bf16x2(silu_f(bf16lo(g[j])) * bf16lo(u[j]), silu_f(bf16hi(g[j])) * bf16hi(u[j]));
+    *reinterpret_cast<u32x4_t*>(out + m * I + c * 8) = o;
+  }
+}
+
+void launch_swiglu(const bf16_t* in, bf16_t* out, long long M, int I, hipStream_t st) {
+  const long long work = M * (I / 8);
+  int blocks = static_cast<int>((work + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(swiglu_kernel, dim3(blocks), dim3(256), 0, st, in, out, M, I);
+}
+
+// ------------------------------------------------- spatio-temporal pooling
+// feats [T][S][C] -> out [(Tn + S)][C]: rows 0..Tn-1 are per-frame means over S
+// (zero rows if Tn > T), rows Tn.. are per-token means over T.  One thread owns
+// one 8-channel chunk of one output row, so both reductions come out of a
+// single launch without atomics.
+__global__ __launch_bounds__(256) void st_pool_kernel(const bf16_t* __restrict__ f,
+                                                      bf16_t* __restrict__ out, int T, int S,
+                                                      int C, int Tn) {
+  const int cpr = C >> 3;
+  const int rows = Tn + S;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * cpr; i += gridDim.x * 256) {
+    const int r = i / cpr, c = i % cpr;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float inv;
+    if (r < Tn) {
+      inv = 1.f / static_cast<float>(S);
+      if (r < T) {
+        for (int s = 0; s < S; ++s) {
+          u32x4_t v = load16(f + (static_cast<size_t>(r) * S + s) * C + c * 8);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc[2 * j] += bf16lo(v[j]); acc[2 * j + 1] += bf16hi(v[j]); }
+        }
+      }
+    } else {
+      inv = 1.f / static_cast<float>(T);
+      const int s = r - Tn;
+      for (int t = 0; t < T; ++t) {
+        u32x4_t v = load16(f + (static_cast<size_t>(t) * S + s) * C + c * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[2 * j] += bf16lo(v[j]); acc[2 * j + 1] += bf16hi(v[j]); }
+      }
+    }
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(acc[2 * j] * inv, acc[2 * j + 1] * inv);
+    *reinterpret_cast<u32x4_t*>(out + static_cast<size_t>(r) * C + c * 8) = o;
+  }
+}
+
+void launch_st_pool(const bf16_t* f, bf16_t* out, int T, int S, int C, int Tn, hipStream_t st) {
+  const int work = (Tn + S) * (C / 8);
+  int blocks = (work + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(st_pool_kernel, dim3(blocks), dim3(256), 0, st, f, out, T, S, C, Tn);
+}
+
+// ----------------------------------------------------------------- argmax
+// Row-wise argmax of an fp32 or bf16 [rows][N] matrix, lowest index on ties.
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const T* __restrict__ x,
+                                                          long long* __restrict__ out, int N) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const T* row = x + static_cast<size_t>(blockIdx.x) * N;
+  float bv = -INFINITY;
+  int bi = 0;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    float v;
+    if constexpr (sizeof(T) == 2) v = bf16_to_f32(row[i]); else v = row[i];
+    if (v > bv) { bv = v; bi = i; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(bv, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sv[wid] = bv; si[wid] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+    out[blockIdx.x] = bi;
+  }
+}
+
+void launch_argmax_rows_f32(const float* x, long long* out, int rows, int N, hipStream_t st) {
+  hipLaunchKernelGGL(argmax_rows_kernel<float>, dim3(rows), dim3(256), 0, st, x, out, N);
+}
+void launch_argmax_rows_bf16(const bf16_t* x, long long* out, int rows, int N, hipStream_t st) {
+  hipLaunchKernelGGL(argmax_rows_kernel<bf16_t>, dim3(rows), dim3(256), 0, st, x, out, N);
+}
+
+// ------------------------------------------- decode step: commit the token
+// Finishes the lm_head argmax from per-block partials, or takes a token chosen
+// by the sampler, then (a) appends it to the output ring at the device-side
+// step counter, (b) sets the EOS flag, (c) gathers its embedding row into the
+// residual-stream buffer for the next step and (d) advances the position.
+// One block per sequence; everything the host would otherwise do between two
+// decode steps, so a replayed graph needs no host round trip.
+__global__ __launch_bounds__(256) void commit_token_kernel(
+    const float* __restrict__ part_val, const int* __restrict__ part_idx, int n_part,
+    const int* __restrict__ sampled, const bf16_t* __restrict__ embed, bf16_t* __restrict__ x,
+    int* __restrict__ out_tokens, int max_out, int* __restrict__ step, int* __restrict__ pos,
+    int* __restrict__ done, int* __restrict__ cur_token, int eos, int H) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ int tok_s;
+  const int b = blockIdx.x;
+  if (sampled) {
+    if (threadIdx.x == 0) tok_s = sampled[b];
+  } else {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n_part; i += 256) {
+      const float v = part_val[b * n_part + i];
+      const int ix = part_idx[b * n_part + i];
+      if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sv[wid] = bv; si[wid] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+      tok_s = bi;
+    }
+  }
+  __syncthreads();
+  const int tok = tok_s;
+  const int st = step[b];
+  if (threadIdx.x == 0) {
+    if (st < max_out) out_tokens[b * max_out + st] = tok;
+    cur_token[b] = tok;
+    if (tok == eos) done[b] = 1;
+  }
+  // embedding row for the next step
+  const int nchunk = H >> 3;
+  for (int c = threadIdx.x; c < nchunk; c += 256)
+    *reinterpret_cast<u32x4_t*>(x + static_cast<size_t>(b) * H + c * 8) =
+        load16(embed + static_cast<size_t>(tok) * H + c * 8);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    step[b] = st + 1;
+    pos[b] = pos[b] + 1;
+  }
+}
+
+void launch_commit_token(const float* part_val, const int* part_idx, int n_part,
+                         const int* sampled, const bf16_t* embed, bf16_t* x, int* out_tokens,
+                         int max_out, int* step, int* pos, int* done, int* cur_token, int eos,
+                         int B, int H, hipStream_t st) {
+  hipLaunchKernelGGL(commit_token_kernel, dim3(B), dim3(256), 0, st, part_val, part_idx, n_part,
+                     sampled, embed, x, out_tokens, max_out, step, pos, done, cur_token, eos, H);
+}
+
+}  // namespace evgpt

@@ -1,0 +1,339 @@
+// Decode-time weight-streaming GEMV family for batch <= 4 token rows.
+//
+//   y[b][n] = epilogue( sum_k W[n][k] * prologue(x)[b][k] )
+//
+// Regime: one token per sequence reads every weight exactly once (13.5 GB per
+// token for a 7B model), so these kernels are pure HBM streaming.  Design:
+//   * weights go straight from HBM to VGPRs with non-temporal 16-byte loads
+//     (no LDS round trip: a weight byte is used by exactly one wave);
+//   * the activation vector (8-22 KB) is staged once per block in LDS, with the
+//     RMSNorm of the producing layer folded into that staging pass, so norm and
+//     projection are one launch;
+//   * one wave owns R=4 output rows at a time and keeps 16 loads (16 KB) in
+//     flight; v_dot2c_f32_bf16 does the MACs without bf16->f32 unpacking;
+//   * epilogues fuse what would otherwise be separate launches: residual add,
+//     SwiGLU (gate/up row pairs), RoPE + KV-cache append (q/k row pairs j,j+64),
+//     fp32 logits + per-block argmax partials.
+// Positions / cache lengths are read from device memory so a captured graph can
+// be replayed for every token.
+#include "common.h"
+#include "../evgpt_kernels.h"
+
+namespace evgpt {
+
+enum { P_NONE = 0, P_RMSNORM = 1 };
+enum { E_STORE = 0, E_RESIDUAL = 1, E_SWIGLU = 2, E_QKV_ROPE = 3, E_LOGITS = 4 };
+
+struct GemvParams {
+  const bf16_t* W;       // [N][K]
+  const bf16_t* x;       // [B][K]
+  const bf16_t* norm_w;  // [K]           (P_RMSNORM)
+  float eps;
+  int N, K;
+  // E_STORE / E_RESIDUAL / E_SWIGLU
+  bf16_t* y;             // [B][N_out]
+  const bf16_t* res;     // [B][N]        (E_RESIDUAL; may alias y)
+  const bf16_t* bias;    // [N] or null   (E_STORE)
+  int act;
+  // E_QKV_ROPE
+  bf16_t* q_out;         // [B][Hq*D]
+  bf16_t* k_cache;       // [B][Hkv][Lmax][D]
+  bf16_t* v_cache;
+  const float* cos_tab;  // [max_pos][D/2]
+  const float* sin_tab;
+  const int* pos;        // [B] device-resident positions
+  int n_q_heads, n_kv_heads, head_dim, l_max;
+  // E_LOGITS
+  float* logits;         // [B][N] or null
+  float* part_val;       // [B][gridDim.x]
+  int* part_idx;
+};
+
+constexpr int R = 4;           // rows per wave
+constexpr int GEMV_WAVES = 4;  // waves per block
+
+template <int E>
+__device__ __forceinline__ void unit_rows(const GemvParams& p, int u, int (&row)[R]) {
+  if constexpr (E == E_SWIGLU) {
+    const int half = p.N >> 1;  // rows [0,half) = gate, [half,N) = up
+    row[0] = 2 * u; row[1] = 2 * u + 1; row[2] = half + 2 * u; row[3] = half + 2 * u + 1;
+  } else if constexpr (E == E_QKV_ROPE) {
+    const int hd = p.head_dim, hh = hd >> 1;
+    const int rot_rows = (p.n_q_heads + p.n_kv_heads) * hd;  // q and k regions rotate
+    const int rot_units = rot_rows >> 2;
+    if (u < rot_units) {
+      const int units_per_head = hd >> 2;  // 2 pairs per unit
+      const int h = u / units_per_head, j = (u % units_per_head) * 2;
+      const int base = h * hd;
+      row[0] = base + j; row[1] = base + j + 1; row[2] = base + hh + j; row[3] = base + hh + j + 1;
+    } else {
+      const int r0 = rot_rows + (u - rot_units) * 4;
+      row[0] = r0; row[1] = r0 + 1; row[2] = r0 + 2; row[3] = r0 + 3;
+    }
+  } else {
+    row[0] = 4 * u; row[1] = 4 * u + 1; row[2] = 4 * u + 2; row[3] = 4 * u + 3;
+  }
+}
+
+template <int B, int P, int E>
+__global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);  // [B][K/8] 16-byte chunks
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int nchunk = p.K >> 3;
+
+  // ---------------- prologue: stage (and normalise) x into LDS ----------------
+  if constexpr (P == P_RMSNORM) {
+    float* red = reinterpret_cast<float*>(smem + static_cast<size_t>(B) * nchunk * 16);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      float ss = 0.f;
+      for (int c = tid; c < nchunk; c += blockDim.x) {
+        u32x4_t v = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float lo = bf16lo(v[i]), hi = bf16hi(v[i]);
+          ss += lo * lo + hi * hi;
+        }
+      }
+      ss = block_sum(ss, red);
+      const float rstd = rsqrtf(ss / static_cast<float>(p.K) + p.eps);
+      for (int c = tid; c < nchunk; c += blockDim.x) {
+        u32x4_t v = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+        u32x4_t w = load16(p.norm_w + c * 8);
+        u32x4_t o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // HF order: round x*rstd to bf16, then multiply by the bf16 weight
+          const float lo = bf16_to_f32(f32_to_bf16(bf16lo(v[i]) * rstd)) * bf16lo(w[i]);
+          const float hi = bf16_to_f32(f32_to_bf16(bf16hi(v[i]) * rstd)) * bf16hi(w[i]);
+          o[i] = pack_bf16x2(lo, hi);
+        }
+        xs[b * nchunk + c] = o;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+      for (int c = tid; c < nchunk; c += blockDim.x)
+        xs[b * nchunk + c] = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+  }
+  __syncthreads();
+
+  // ------------------------------ main loop ------------------------------
+  const int n_units = (p.N + R - 1) / R;
+  float best_val[B];
+  int best_idx[B];
+  if constexpr (E == E_LOGITS) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) { best_val[b] = -INFINITY; best_idx[b] = 0; }
+  }
+
+  for (int u = blockIdx.x * GEMV_WAVES + wid; u < n_units; u += gridDim.x * GEMV_WAVES) {
+    int row[R];
+    unit_rows<E>(p, u, row);
+    const bf16_t* wp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int rr = row[r] < p.N ? row[r] : p.N - 1;  // clamp; out-of-range rows are discarded
+      wp[r] = p.W + static_cast<size_t>(rr) * p.K;
+    }
+    float acc[R][B];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
+
+#pragma unroll 4
+    for (int c = lane; c < nchunk; c += 64) {
+      u32x4_t wv[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) wv[r] = load_stream16(wp[r] + c * 8);
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const u32x4_t xv = xs[b * nchunk + c];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r][b] = dot8_bf16(wv[r], xv, acc[r][b]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc[r][b] = wave_sum(acc[r][b]);
+
+    // ------------------------------ epilogues ------------------------------
+    if constexpr (E == E_LOGITS) {
+#pragma unroll
+      for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (row[r] < p.N) {
+            // logits are rounded to bf16 like the reference's lm_head output
+            const float v = bf16_to_f32(f32_to_bf16(acc[r][b]));
+            if (lane == 0 && p.logits) p.logits[static_cast<size_t>(b) * p.N + row[r]] = v;
+            if (v > best_val[b]) { best_val[b] = v; best_idx[b] = row[r]; }
+          }
+        }
+    } else if (lane == 0) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        if constexpr (E == E_STORE) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            if (row[r] < p.N) {
+              float v = acc[r][b];
+              if (p.bias) v += bf16_to_f32(p.bias[row[r]]);
+              v = apply_act(v, p.act);
+              p.y[static_cast<size_t>(b) * p.N + row[r]] = f32_to_bf16(v);
+            }
+          }
+        } else if constexpr (E == E_RESIDUAL) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            if (row[r] < p.N) {
+              const size_t o = static_cast<size_t>(b) * p.N + row[r];
+              const float v = bf16_to_f32(f32_to_bf16(acc[r][b])) + bf16_to_f32(p.res[o]);
+              p.y[o] = f32_to_bf16(v);
+            }
+          }
+        } else if constexpr (E == E_SWIGLU) {
+          const int half = p.N >> 1;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if (row[i] < half) {
+              const float g = bf16_to_f32(f32_to_bf16(acc[i][b]));
+              const float up = bf16_to_f32(f32_to_bf16(acc[2 + i][b]));
+              p.y[static_cast<size_t>(b) * half + row[i]] = f32_to_bf16(silu_f(g) * up);
+            }
+          }
+        } else if constexpr (E == E_QKV_ROPE) {
+          const int hd = p.head_dim, hh = hd >> 1;
+          const int q_rows = p.n_q_heads * hd, k_rows = p.n_kv_heads * hd;
+          const int pos = p.pos[b];
+          if (row[0] < q_rows + k_rows) {
+            const int h_all = row[0] / hd, j = row[0] % hd;  // j < hh
+            bf16_t* dst;
+            if (h_all < p.n_q_heads) {
+              dst = p.q_out + static_cast<size_t>(b) * q_rows + h_all * hd;
+            } else {
+              const int h = h_all - p.n_q_heads;
+              dst = p.k_cache + ((static_cast<size_t>(b) * p.n_kv_heads + h) * p.l_max + pos) * hd;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const float c = p.cos_tab[static_cast<size_t>(pos) * hh + j + i];
+              const float s = p.sin_tab[static_cast<size_t>(pos) * hh + j + i];
+              const float x1 = bf16_to_f32(f32_to_bf16(acc[i][b]));
+              const float x2 = bf16_to_f32(f32_to_bf16(acc[2 + i][b]));
+              dst[j + i] = f32_to_bf16(x1 * c - x2 * s);
+              dst[j + i + hh] = f32_to_bf16(x2 * c + x1 * s);
+            }
+          } else {
+            const int vr = row[0] - q_rows - k_rows;
+            const int h = vr / hd, j = vr % hd;
+            bf16_t* dst = p.v_cache + ((static_cast<size_t>(b) * p.n_kv_heads + h) * p.l_max + pos) * hd;
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[j + r] = f32_to_bf16(acc[r][b]);
+          }
+        }
+      }
+    }
+  }
+
+  if constexpr (E == E_LOGITS) {
+    // block-level argmax partial: (value, lowest index on ties)
+    __shared__ float sv[GEMV_WAVES][B];
+    __shared__ int si[GEMV_WAVES][B];
+    if (lane == 0) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) { sv[wid][b] = best_val[b]; si[wid][b] = best_idx[b]; }
+    }
+    __syncthreads();
+    if (tid < B) {
+      float bv = sv[0][tid];
+      int bi = si[0][tid];
+      for (int w = 1; w < GEMV_WAVES; ++w)
+        if (sv[w][tid] > bv || (sv[w][tid] == bv && si[w][tid] < bi)) { bv = sv[w][tid]; bi = si[w][tid]; }
+      p.part_val[tid * gridDim.x + blockIdx.x] = bv;
+      p.part_idx[tid * gridDim.x + blockIdx.x] = bi;
+    }
+  }
+}
+
+template <int P, int E>
+static void launch_b(const GemvParams& p, int B, int grid, hipStream_t st) {
+  const size_t smem = static_cast<size_t>(B) * (p.K / 8) * 16 + (P == P_RMSNORM ? 64 : 0);
+  dim3 g(grid), b(GEMV_WAVES * 64);
+  switch (B) {
+    case 1: hipLaunchKernelGGL((gemv_kernel<1, P, E>), g, b, smem, st, p); break;
+    case 2: hipLaunchKernelGGL((gemv_kernel<2, P, E>), g, b, smem, st, p); break;
+    case 3: hipLaunchKernelGGL((gemv_kernel<3, P, E>), g, b, smem, st, p); break;
+    case 4: hipLaunchKernelGGL((gemv_kernel<4, P, E>), g, b, smem, st, p); break;
+    default: break;
+  }
+}
+
+static int gemv_grid(int N) {
+  const int units = (N + R - 1) / R;
+  int blocks = (units + GEMV_WAVES - 1) / GEMV_WAVES;
+  const int cap = 256 * 8;  // 8 blocks per CU; the rest is a grid-stride loop
+  return blocks < cap ? blocks : cap;
+}
+
+int gemv_max_batch() { return 4; }
+
+int gemv_logits_grid(int N) { return gemv_grid(N); }
+
+void launch_gemv(const bf16_t* W, const bf16_t* x, bf16_t* y, const bf16_t* bias,
+                 const bf16_t* res, const bf16_t* norm_w, float eps, int act, int B, int N,
+                 int K, hipStream_t st) {
+  GemvParams p{};
+  p.W = W; p.x = x; p.y = y; p.bias = bias; p.res = res; p.norm_w = norm_w; p.eps = eps;
+  p.act = act; p.N = N; p.K = K;
+  const int grid = gemv_grid(N);
+  if (res) {
+    if (norm_w) launch_b<P_RMSNORM, E_RESIDUAL>(p, B, grid, st);
+    else launch_b<P_NONE, E_RESIDUAL>(p, B, grid, st);
+  } else {
+    if (norm_w) launch_b<P_RMSNORM, E_STORE>(p, B, grid, st);
+    else launch_b<P_NONE, E_STORE>(p, B, grid, st);
+  }
+}
+
+void launch_gemv_swiglu(const bf16_t* W_gate_up, const bf16_t* x, bf16_t* y,
+                        const bf16_t* norm_w, float eps, int B, int inter, int K,
+                        hipStream_t st) {
+  GemvParams p{};
+  p.W = W_gate_up; p.x = x; p.y = y; p.norm_w = norm_w; p.eps = eps; p.N = 2 * inter; p.K = K;
+  const int grid = gemv_grid(2 * inter);
+  if (norm_w) launch_b<P_RMSNORM, E_SWIGLU>(p, B, grid, st);
+  else launch_b<P_NONE, E_SWIGLU>(p, B, grid, st);
+}
+
+void launch_gemv_qkv_rope(const bf16_t* W_qkv, const bf16_t* x, const bf16_t* norm_w, float eps,
+                          bf16_t* q_out, bf16_t* k_cache, bf16_t* v_cache, const float* cos_tab,
+                          const float* sin_tab, const int* pos, int B, int n_q_heads,
+                          int n_kv_heads, int head_dim, int l_max, int K, hipStream_t st) {
+  GemvParams p{};
+  p.W = W_qkv; p.x = x; p.norm_w = norm_w; p.eps = eps; p.K = K;
+  p.N = (n_q_heads + 2 * n_kv_heads) * head_dim;
+  p.q_out = q_out; p.k_cache = k_cache; p.v_cache = v_cache; p.cos_tab = cos_tab;
+  p.sin_tab = sin_tab; p.pos = pos; p.n_q_heads = n_q_heads; p.n_kv_heads = n_kv_heads;
+  p.head_dim = head_dim; p.l_max = l_max;
+  const int grid = gemv_grid(p.N);
+  if (norm_w) launch_b<P_RMSNORM, E_QKV_ROPE>(p, B, grid, st);
+  else launch_b<P_NONE, E_QKV_ROPE>(p, B, grid, st);
+}
+
+void launch_gemv_logits(const bf16_t* W, const bf16_t* x, const bf16_t* norm_w, float eps,
+                        float* logits, float* part_val, int* part_idx, int B, int N, int K,
+                        hipStream_t st) {
+  GemvParams p{};
+  p.W = W; p.x = x; p.norm_w = norm_w; p.eps = eps; p.N = N; p.K = K;
+  p.logits = logits; p.part_val = part_val; p.part_idx = part_idx;
+  const int grid = gemv_grid(N);
+  if (norm_w) launch_b<P_RMSNORM, E_LOGITS>(p, B, grid, st);
+  else launch_b<P_NONE, E_LOGITS>(p, B, grid, st);
+}
+
+}  // namespace evgpt

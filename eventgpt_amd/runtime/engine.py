@@ -1,0 +1,301 @@
+"""GenerationEngine — the MI355X serving path of the decoder.
+
+What it is: a static-memory executor for prefill + autoregressive decode of a
+LLaMA-family decoder whose weights live in an ``EventChatModel``.
+
+  * weights are re-packed once (``q|k|v`` rows in one matrix, ``gate|up`` rows
+    in one matrix); the module's parameters are re-pointed at views of the
+    packed storage, so there is one copy in HBM;
+  * the KV cache is pre-allocated ``[layers][B, Hkv, Lmax, D]``; sequence
+    positions, the step counter, EOS flags and the token ring live in device
+    memory and are advanced by the kernels themselves;
+  * one decode step is 6 launches per layer (fused norm+QKV+RoPE+cache append,
+    split-KV attention, combine, o_proj+residual, fused norm+gate/up+SwiGLU,
+    down+residual) plus lm_head/argmax and a token-commit kernel that also
+    gathers the next embedding — no host work between steps;
+  * the whole step is captured once into a HIP graph and replayed per token;
+    the host only polls the EOS flag every ``poll_every`` tokens.
+
+Prefill runs the same weights through the MFMA GEMM and the fused causal
+attention kernel and appends to the same cache.  The reference's equivalent is
+HF ``generate`` / its hand-rolled loops with one host sync and several
+allocations per token (pipeline/benchmark_e2e/benchmark_e2e_wallclock.py:417-472).
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import List, Optional
+
+import torch
+
+from .. import ops
+
+
+@dataclasses.dataclass
+class _Layer:
+    w_qkv: torch.Tensor
+    w_o: torch.Tensor
+    w_gate_up: torch.Tensor
+    w_down: torch.Tensor
+    norm1: torch.Tensor
+    norm2: torch.Tensor
+    k_cache: torch.Tensor
+    v_cache: torch.Tensor
+
+
+def _pad_rows(w: torch.Tensor, mult: int) -> torch.Tensor:
+    pad = (-w.shape[0]) % mult
+    if pad == 0:
+        return w
+    return torch.cat([w, w.new_zeros(pad, w.shape[1])])
+
+
+class GenerationEngine:
+    def __init__(self, model, max_len: int = 2560, max_batch: int = 1, nsplit: int = 8,
+                 use_graph: bool = True, max_new_tokens: int = 1024, poll_every: int = 16):
+        from ..ops import hip  # raises if the extension is missing
+        self.raw = hip.raw
+        cfg = model.config
+        dev = model.device
+        if dev.type != "cuda":
+            raise RuntimeError("GenerationEngine needs the model on a GPU")
+        if model.dtype != torch.bfloat16:
+            raise RuntimeError("GenerationEngine runs bf16 weights")
+        self.model = model
+        self.cfg = cfg
+        self.device = dev
+        self.B = max_batch
+        self.H = cfg.hidden_size
+        self.Hq = cfg.num_attention_heads
+        self.Hkv = cfg.num_key_value_heads
+        self.D = cfg.head_dim
+        self.I = cfg.intermediate_size
+        self.V = model.lm_head.weight.shape[0]
+        self.eps = float(cfg.rms_norm_eps)
+        self.l_max = max_len
+        self.nsplit = nsplit
+        self.use_graph = use_graph
+        self.max_out = max_new_tokens
+        self.poll_every = poll_every
+        self.scale = 1.0 / math.sqrt(self.D)
+        if self.D not in (64, 128):
+            raise ValueError("head_dim must be 64 or 128 for the HIP attention kernels")
+        if self.H % 64 or self.I % 8:
+            raise ValueError("hidden size must be a multiple of 64, intermediate of 8")
+
+        self.layers: List[_Layer] = []
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        with torch.no_grad():
+            for lyr in model.model.layers:
+                at, mlp = lyr.self_attn, lyr.mlp
+                w_qkv = torch.cat([at.q_proj.weight.data, at.k_proj.weight.data,
+                                   at.v_proj.weight.data]).contiguous()
+                nq, nk = self.Hq * self.D, self.Hkv * self.D
+                at.q_proj.weight.data = w_qkv[:nq]
+                at.k_proj.weight.data = w_qkv[nq:nq + nk]
+                at.v_proj.weight.data = w_qkv[nq + nk:]
+                w_gu = torch.cat([mlp.gate_proj.weight.data, mlp.up_proj.weight.data]).contiguous()
+                mlp.gate_proj.weight.data = w_gu[:self.I]
+                mlp.up_proj.weight.data = w_gu[self.I:]
+                self.layers.append(_Layer(
+                    w_qkv, at.o_proj.weight.data, w_gu, mlp.down_proj.weight.data,
+                    lyr.input_layernorm.weight.data, lyr.post_attention_layernorm.weight.data,
+                    torch.zeros(self.B, self.Hkv, max_len, self.D, **bf),
+                    torch.zeros(self.B, self.Hkv, max_len, self.D, **bf)))
+        self.final_norm = model.model.norm.weight.data
+        self.lm_head = model.lm_head.weight.data
+        self.embed = model.model.embed_tokens.weight.data
+        cos, sin = ops.rope_tables(max_len, self.D, cfg.rope_theta, dev)
+        self.cos, self.sin = cos.contiguous(), sin.contiguous()
+
+        B = self.B
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.x = torch.zeros(B, self.H, **bf)           # residual stream of the decode step
+        self.q = torch.zeros(B, self.Hq * self.D, **bf)
+        self.attn = torch.zeros(B, self.Hq * self.D, **bf)
+        self.h = torch.zeros(B, self.I, **bf)
+        self.part_o = torch.zeros(B * self.Hq * nsplit * self.D, **f32)
+        self.part_ml = torch.zeros(B * self.Hq * nsplit * 2, **f32)
+        self.n_part = int(self.raw.logits_partials(self.V))
+        self.part_val = torch.zeros(B * self.n_part, **f32)
+        self.part_idx = torch.zeros(B * self.n_part, **i32)
+        self.logits = torch.zeros(B, self.V, **f32)
+        self.out_tokens = torch.zeros(B, self.max_out, **i32)
+        self.step = torch.zeros(B, **i32)
+        self.pos = torch.zeros(B, **i32)
+        self.done = torch.zeros(B, **i32)
+        self.cur_token = torch.zeros(B, **i32)
+        self.sampled = torch.zeros(B, **i32)
+        self.eos = int(cfg.eos_token_id if cfg.eos_token_id is not None else -1)
+        self._graph_greedy = None
+        self._graph_logits = None
+
+    # ------------------------------------------------------------------ state
+    def reset(self) -> None:
+        for t in (self.step, self.pos, self.done, self.cur_token):
+            t.zero_()
+
+    @property
+    def kv_bytes_per_token(self) -> int:
+        return 2 * len(self.layers) * self.Hkv * self.D * 2
+
+    def past_key_values(self, batch: int = 0):
+        """HF-style tuple of ``(k, v)`` views ``[1, Hkv, L, D]`` of the live cache."""
+        n = int(self.pos[batch].item())
+        return tuple((l.k_cache[batch:batch + 1, :, :n], l.v_cache[batch:batch + 1, :, :n])
+                     for l in self.layers)
+
+    # ---------------------------------------------------------------- prefill
+    @torch.no_grad()
+    def prefill(self, embeds: torch.Tensor, batch: int = 0, start: Optional[int] = None,
+                select: Optional[str] = "greedy", return_hidden: bool = False):
+        """Run ``embeds [S, H]`` through the decoder, appending to sequence ``batch``'s
+        cache from position ``start`` (default: its current length).
+
+        ``select="greedy"`` picks the next token from the last row and commits it
+        exactly as a decode step would; ``"logits"`` leaves fp32 logits of the last
+        row in ``self.logits`` for a sampler (commit with ``_commit_sampled``);
+        ``None`` only fills the cache.  Returns the last-layer hidden states
+        ``[S, H]`` (before the final norm) if ``return_hidden``.
+        """
+        raw = self.raw
+        S = embeds.shape[0]
+        if start is None:
+            start = int(self.pos[batch].item())
+        if start + S > self.l_max:
+            raise ValueError(f"sequence of {start + S} tokens exceeds the cache ({self.l_max})")
+        x = embeds.to(torch.bfloat16).contiguous().view(1, S, self.H)
+        pos0 = torch.tensor([start], dtype=torch.int32, device=self.device)
+        kv_len = torch.tensor([start + S], dtype=torch.int32, device=self.device)
+        q = torch.empty(1, S, self.Hq, self.D, dtype=torch.bfloat16, device=self.device)
+        o = torch.empty_like(q)
+        for l in self.layers:
+            kc, vc = l.k_cache[batch:batch + 1], l.v_cache[batch:batch + 1]
+            xn = raw.rmsnorm(x, l.norm1, self.eps)
+            qkv = raw.linear(xn, l.w_qkv, None, None, 0, False)
+            raw.prefill_rope_kv(qkv, q, kc, vc, self.cos, self.sin, pos0, self.Hq, self.Hkv, self.D)
+            raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
+            x = raw.linear(o.view(1, S, self.Hq * self.D), l.w_o, None, x, 0, False)
+            xn = raw.rmsnorm(x, l.norm2, self.eps)
+            gu = raw.linear(xn, l.w_gate_up, None, None, 0, False)
+            x = raw.linear(raw.swiglu(gu), l.w_down, None, x, 0, False)
+        if select is None:
+            self.pos[batch] = start + S
+        else:
+            # the commit kernel advances pos by one, like a decode step does
+            self.pos[batch] = start + S - 1
+            self.x[batch].copy_(x[0, -1])
+            self._logits_and_commit(greedy=(select == "greedy"))
+        return x[0] if return_hidden else None
+
+    # ------------------------------------------------------------ decode step
+    def _layers_step(self) -> None:
+        raw = self.raw
+        for l in self.layers:
+            raw.decode_qkv(self.x, l.norm1, l.w_qkv, self.q, l.k_cache, l.v_cache, self.cos,
+                           self.sin, self.pos, self.eps, self.Hq, self.Hkv, self.D)
+            raw.decode_attn(self.q, l.k_cache, l.v_cache, self.attn, self.part_o, self.part_ml,
+                            self.pos, self.nsplit, self.scale)
+            raw.decode_gemv_residual(l.w_o, self.attn, self.x)
+            raw.decode_mlp_up(l.w_gate_up, self.x, l.norm2, self.eps, self.h)
+            raw.decode_gemv_residual(l.w_down, self.h, self.x)
+
+    def _logits_and_commit(self, greedy: bool, want_logits: bool = False) -> None:
+        raw = self.raw
+        raw.decode_logits(self.lm_head, self.x, self.final_norm, self.eps,
+                          None if (greedy and not want_logits) else self.logits,
+                          self.part_val, self.part_idx)
+        if greedy:
+            raw.commit_token(self.part_val, self.part_idx, self.n_part, None, self.embed, self.x,
+                             self.out_tokens, self.step, self.pos, self.done, self.cur_token,
+                             self.eos)
+
+    def _commit_sampled(self) -> None:
+        self.raw.commit_token(self.part_val, self.part_idx, self.n_part, self.sampled, self.embed,
+                              self.x, self.out_tokens, self.step, self.pos, self.done,
+                              self.cur_token, self.eos)
+
+    def _step_greedy(self) -> None:
+        self._layers_step()
+        self._logits_and_commit(greedy=True)
+
+    def _step_logits(self) -> None:
+        self._layers_step()
+        self._logits_and_commit(greedy=False)
+
+    def _capture(self, fn):
+        """Capture ``fn`` into a HIP graph.  Warm-up and capture advance the device
+        counters, so they are snapshotted and restored."""
+        saved = [t.clone() for t in (self.step, self.pos, self.done, self.cur_token, self.x)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()  # warm-up (first-launch module load) outside the capture
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        for t, s in zip((self.step, self.pos, self.done, self.cur_token, self.x), saved):
+            t.copy_(s)
+        torch.cuda.synchronize()
+        return g
+
+    def decode_step(self, greedy: bool = True) -> None:
+        """Advance every sequence by one token (graph replay when enabled)."""
+        if not self.use_graph:
+            (self._step_greedy if greedy else self._step_logits)()
+            return
+        if greedy:
+            if self._graph_greedy is None:
+                self._graph_greedy = self._capture(self._step_greedy)
+            self._graph_greedy.replay()
+        else:
+            if self._graph_logits is None:
+                self._graph_logits = self._capture(self._step_logits)
+            self._graph_logits.replay()
+
+    # --------------------------------------------------------------- generate
+    def _sample_and_commit(self, temperature: float, top_p: float, generator) -> None:
+        tok = ops.sample_top_p(self.logits, temperature, top_p, generator)
+        self.sampled.copy_(tok.to(torch.int32))
+        self._commit_sampled()
+
+    @torch.no_grad()
+    def generate(self, embeds: torch.Tensor, max_new_tokens: int = 512, temperature: float = 0.0,
+                 top_p: float = 1.0, eos_token_id: Optional[int] = None,
+                 generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """Greedy / nucleus generation for one sequence; returns new token ids (long).
+
+        Greedy decoding replays one captured graph per token and syncs with the
+        host only every ``poll_every`` tokens to read the EOS flag.  Sampling
+        replays the layers+logits graph, then draws the token on the device.
+        """
+        if eos_token_id is not None:
+            self.eos = int(eos_token_id)
+        if max_new_tokens > self.max_out:
+            raise ValueError(f"max_new_tokens {max_new_tokens} > engine ring {self.max_out}")
+        self.reset()
+        greedy = temperature <= 0
+        self.prefill(embeds, select="greedy" if greedy else "logits")
+        if not greedy:
+            self._sample_and_commit(temperature, top_p, generator)
+        n = 1
+        budget = min(max_new_tokens, self.l_max - embeds.shape[0])
+        while n < budget:
+            chunk = min(self.poll_every, budget - n)
+            for _ in range(chunk):
+                self.decode_step(greedy)
+                if not greedy:
+                    self._sample_and_commit(temperature, top_p, generator)
+            n += chunk
+            if int(self.done[0].item()):
+                break
+        toks = self.out_tokens[0, :n].to(torch.long)
+        if self.eos >= 0:
+            hit = (toks == self.eos).nonzero()
+            if hit.numel():
+                toks = toks[: int(hit[0]) + 1]
+        return toks

@@ -1,0 +1,146 @@
+"""HIP kernels vs the plain-PyTorch fp32 reference of the same op."""
+import math
+
+import pytest
+import torch
+
+from eventgpt_amd.ops import reference as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    from eventgpt_amd.ops import hip
+    return hip
+
+
+def _rand(*shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device=dev).manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, device=dev, generator=g) * scale).to(torch.bfloat16)
+
+
+def _close(a, b, atol, rtol):
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.4g}, worst excess {(err - tol).max().item():.4g}"
+
+
+@pytest.mark.parametrize("rows,H", [(1, 4096), (7, 512), (641, 4096), (3, 1024)])
+def test_rmsnorm(dev, rows, H):
+    x, w = _rand(rows, H, dev=dev), _rand(H, dev=dev, seed=1)
+    _close(_hip().rmsnorm(x, w, 1e-6), ref.rmsnorm(x, w, 1e-6), 2e-2, 2e-2)
+
+
+def test_add_rmsnorm(dev):
+    x, r, w = _rand(33, 4096, dev=dev), _rand(33, 4096, dev=dev, seed=2), _rand(4096, dev=dev, seed=1)
+    y, ro = _hip().add_rmsnorm(x, r, w, 1e-6)
+    y_ref, r_ref = ref.add_rmsnorm(x, r, w, 1e-6)
+    assert torch.equal(ro, r_ref)
+    _close(y, y_ref, 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("rows,H", [(577, 1024), (5, 64), (1, 4096)])
+def test_layernorm(dev, rows, H):
+    x, w, b = _rand(rows, H, dev=dev), _rand(H, dev=dev, seed=1), _rand(H, dev=dev, seed=2)
+    _close(_hip().layernorm(x, w, b, 1e-5), ref.layernorm(x, w, b, 1e-5), 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (2, 1003, 512), (4, 256, 11008), (3, 12288, 4096)])
+def test_linear_gemv(dev, M, N, K):
+    x, w = _rand(M, K, dev=dev), _rand(N, K, dev=dev, scale=0.02, seed=3)
+    if N % 4:
+        pytest.skip("gemv path needs N % 4 == 0; covered by the GEMM test")
+    y = _hip().linear(x, w)
+    _close(y, ref.linear(x, w), 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(641, 4096, 4096), (64, 128, 64), (17, 1003, 512),
+                                   (130, 200, 1408), (577, 1024, 640), (32, 4096, 4096),
+                                   (300, 12288, 4096), (5, 32003, 4096)])
+def test_linear_gemm(dev, M, N, K):
+    x, w = _rand(M, K, dev=dev), _rand(N, K, dev=dev, scale=0.02, seed=3)
+    y = _hip().linear(x, w)
+    _close(y, ref.linear(x, w), 2e-2, 2e-2)
+
+
+def test_linear_gemm_asymmetric_identity(dev):
+    """A = I with an asymmetric W catches a transposed accumulator map."""
+    K = 128
+    x = torch.eye(K, device=dev, dtype=torch.bfloat16)
+    w = (torch.arange(200 * K, device=dev).reshape(200, K) % 251 - 125).to(torch.bfloat16)
+    y = _hip().linear(x, w)
+    assert torch.equal(y.float(), w.float().t())
+
+
+@pytest.mark.parametrize("act", ["gelu", "quick_gelu", "silu", None])
+def test_linear_epilogue(dev, act):
+    M, N, K = 70, 264, 256
+    x, w = _rand(M, K, dev=dev), _rand(N, K, dev=dev, scale=0.05, seed=3)
+    b, r = _rand(N, dev=dev, seed=4), _rand(M, N, dev=dev, seed=5)
+    _close(_hip().linear(x, w, b, act, r), ref.linear(x, w, b, act, r), 3e-2, 3e-2)
+    x1 = x[:2].contiguous()
+    _close(_hip().linear(x1, w, b, act, r[:2].contiguous()), ref.linear(x1, w, b, act, r[:2]), 3e-2, 3e-2)
+
+
+def test_linear_pads_k(dev):
+    x, w = _rand(100, 588, dev=dev), _rand(1024, 588, dev=dev, scale=0.05, seed=3)
+    _close(_hip().linear(x, w), ref.linear(x, w), 2e-2, 2e-2)
+
+
+def test_linear_f32_out(dev):
+    x, w = _rand(22, 4096, dev=dev), _rand(1003, 4096, dev=dev, scale=0.02, seed=3)
+    y = _hip().linear(x, w, out_f32=True)
+    assert y.dtype == torch.float32
+    _close(y, x.float() @ w.float().t(), 1e-2, 1e-2)
+
+
+def test_swiglu(dev):
+    gu = _rand(37, 2 * 1408, dev=dev)
+    _close(_hip().swiglu(gu), ref.swiglu(gu), 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_rope(dev, D):
+    B, S, H = 2, 37, 4
+    x = _rand(B, S, H, D, dev=dev)
+    pos = torch.randint(0, 900, (B, S), device=dev)
+    cos, sin = ref.rope_tables(1024, D, 10000.0, dev)
+    _close(_hip().apply_rope(x, pos, cos, sin), ref.apply_rope(x, pos, cos, sin), 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("D,H,Hkv,Sq,Sk,causal", [
+    (128, 4, 4, 641, 641, True), (128, 8, 2, 100, 100, True), (128, 2, 2, 6, 700, True),
+    (64, 16, 16, 577, 577, False), (64, 4, 4, 50, 50, False), (128, 2, 2, 64, 64, True),
+    (128, 2, 2, 1, 130, True), (64, 2, 2, 130, 259, True)])
+def test_attention(dev, D, H, Hkv, Sq, Sk, causal):
+    B = 2
+    q, k, v = _rand(B, Sq, H, D, dev=dev), _rand(B, Sk, Hkv, D, dev=dev, seed=1), \
+        _rand(B, Sk, Hkv, D, dev=dev, seed=2)
+    rep = H // Hkv
+    kr, vr = k.repeat_interleave(rep, 2), v.repeat_interleave(rep, 2)
+    o_ref = ref.attention(q, kr, vr, causal, q_offset=Sk - Sq)
+    o = _hip().attention(q, k, v, causal, None, Sk - Sq)
+    _close(o, o_ref, 2e-2, 2e-2)
+
+
+def test_attention_spike_rescale(dev):
+    """A late key with a huge score forces the online-softmax rescale branch."""
+    B, S, H, D = 1, 200, 2, 128
+    q, k, v = _rand(B, S, H, D, dev=dev), _rand(B, S, H, D, dev=dev, seed=1), _rand(B, S, H, D, dev=dev, seed=2)
+    k[0, 150] = q[0, 199] * 4.0
+    _close(_hip().attention(q, k, v, True, None, 0), ref.attention(q, k, v, True), 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("T,Tn", [(5, 5), (1, 1), (3, 5), (5, 2)])
+def test_st_pool(dev, T, Tn):
+    f = _rand(T, 577, 4096, dev=dev)
+    _close(_hip().spatio_temporal_pool(f, Tn), ref.spatio_temporal_pool(f, Tn), 1e-2, 1e-2)
+
+
+def test_argmax(dev):
+    x = torch.randn(5, 32003, device=dev)
+    assert torch.equal(_hip().argmax_last(x), x.argmax(-1))
+    xb = x.to(torch.bfloat16)
+    got = _hip().argmax_last(xb)
+    assert torch.equal(xb.float().gather(1, got[:, None]), xb.float().max(-1, keepdim=True).values)
