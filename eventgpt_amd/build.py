@@ -30,7 +30,10 @@ ARCH = "gfx950"
 
 # -packed-fp32-ops is disabled on purpose: some packed-fp32 forms have produced
 # wrong results on this hardware pool, so the compiler must not emit them.
-HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffast-math",
+# No -ffast-math: the kernels use +/-inf as softmax / argmax sentinels, and
+# finite-math-only lets the compiler fold `x == -INFINITY` away (NaNs follow).
+HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-math-errno",
+             "-ffp-contract=fast",
              "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
              "-Wno-unused-result", "-Wno-unknown-warning-option", "-Wno-unused-command-line-argument",
              "-DNDEBUG"]

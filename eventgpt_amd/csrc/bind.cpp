@@ -112,7 +112,7 @@ Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bia
     evgpt::launch_gemm_bf16(bptr(x), bptr(w), out_f32 ? nullptr : bptr_mut(y),
                             out_f32 ? y.data_ptr<float>() : nullptr, bptr_opt(bias),
                             bptr_opt(res), (int)M, (int)N, (int)K, (int)K, (int)K, (int)N, (int)act,
-                            st);
+                            nullptr, nullptr, st);
   }
   return y;
 }
@@ -328,7 +328,7 @@ void commit_token(const Tensor& part_val, const Tensor& part_idx, int64_t n_part
                              bptr(embed), bptr_mut(x), out_tokens.data_ptr<int>(),
                              (int)out_tokens.size(1), step.data_ptr<int>(), pos.data_ptr<int>(),
                              done.data_ptr<int>(), cur_token.data_ptr<int>(), (int)eos, (int)B,
-                             (int)H, cur_stream());
+                             (int)H, (int)embed.size(0), cur_stream());
 }
 
 // qkv [B,S,(Hq+2Hkv)*D] -> q_out [B,S,Hq*D] (rotated) + cache append at pos0[b]+s
@@ -348,6 +348,121 @@ void prefill_rope_kv(const Tensor& qkv, const Tensor& q_out, const Tensor& k_cac
                                 cos.data_ptr<float>(), sin.data_ptr<float>(), pos0.data_ptr<int>(),
                                 (int)B, (int)S, (int)Hq, (int)Hkv, (int)D, (int)k_cache.size(2),
                                 cur_stream());
+}
+
+// Row argmax of (x @ w^T + bias) without materialising the product: the GEMM
+// epilogue leaves per-(row, column-slab) partials; returns (val [M,P], idx [M,P]).
+std::tuple<Tensor, Tensor> linear_argmax_partials(const Tensor& x, const Tensor& w,
+                                                   const c10::optional<Tensor>& bias) {
+  check_bf16(x, "x"); check_bf16(w, "weight");
+  const int64_t K = x.size(-1), N = w.size(0), M = x.numel() / K;
+  TORCH_CHECK(w.dim() == 2 && w.size(1) == K && K % 64 == 0 && M >= 1,
+              "linear_argmax: K must be a multiple of 64");
+  if (bias.has_value()) { check_bf16(*bias, "bias"); TORCH_CHECK(bias->numel() == N); }
+  const int64_t P = evgpt::gemm_argmax_partials((int)M, (int)N);
+  Tensor val = at::empty({M, P}, x.options().dtype(at::kFloat));
+  Tensor idx = at::empty({M, P}, x.options().dtype(at::kInt));
+  evgpt::launch_gemm_bf16(bptr(x), bptr(w), nullptr, nullptr, bptr_opt(bias), nullptr, (int)M,
+                          (int)N, (int)K, (int)K, (int)K, (int)N, 0, val.data_ptr<float>(),
+                          idx.data_ptr<int>(), cur_stream());
+  return {val, idx};
+}
+
+// ------------------------------------------------------------ event front end
+// x,y,p int32 [n]; returns uint8 [T,H,W,3].  mode 0: last event wins, 1: negative wins.
+Tensor event_raster(const Tensor& x, const Tensor& y, const Tensor& p, int64_t n_slices, int64_t H,
+                    int64_t W, int64_t mode) {
+  check_i32(x, "x"); check_i32(y, "y"); check_i32(p, "p");
+  const int64_t n = x.numel();
+  TORCH_CHECK(y.numel() == n && p.numel() == n && n_slices >= 1 && H >= 1 && W >= 1);
+  TORCH_CHECK(n < (1ll << 30), "event_raster: at most 2^30 events per call");
+  Tensor keys = at::full({n_slices, H, W}, mode == 0 ? -1 : 0, x.options());
+  Tensor img = at::empty({n_slices, H, W, 3}, x.options().dtype(at::kByte));
+  evgpt::launch_event_raster(x.data_ptr<int>(), y.data_ptr<int>(), p.data_ptr<int>(), (int)n,
+                             (int)n_slices, (int)H, (int)W, keys.data_ptr<int>(),
+                             img.data_ptr<uint8_t>(), (int)mode, cur_stream());
+  return img;
+}
+
+// returns (hist int32 [bins,2,H,W], voxel fp32 [bins,H,W])
+std::tuple<Tensor, Tensor> event_voxel(const Tensor& x, const Tensor& y, const Tensor& p,
+                                       const Tensor& t, int64_t t0, int64_t span, int64_t bins,
+                                       int64_t H, int64_t W, bool signed_mode, bool by_count) {
+  check_i32(x, "x"); check_i32(y, "y"); check_i32(p, "p");
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kLong && t.is_contiguous());
+  const int64_t n = x.numel();
+  TORCH_CHECK(y.numel() == n && p.numel() == n && t.numel() == n && bins >= 1);
+  Tensor hist = at::zeros({bins, 2, H, W}, x.options());
+  Tensor vox = at::zeros({bins, H, W}, x.options().dtype(at::kFloat));
+  evgpt::launch_event_voxel(x.data_ptr<int>(), y.data_ptr<int>(), p.data_ptr<int>(),
+                            reinterpret_cast<const long long*>(t.data_ptr<int64_t>()), (int)n,
+                            (long long)t0, (long long)span, (int)bins, (int)H, (int)W,
+                            hist.data_ptr<int>(), vox.data_ptr<float>(), signed_mode ? 1 : 0,
+                            by_count ? 1 : 0, cur_stream());
+  return {hist, vox};
+}
+
+// img uint8 [T,H,W,3] -> bf16 [T,3,S,S]; tables are int32 GPU tensors
+Tensor clip_preprocess(const Tensor& img, const Tensor& hstart, const Tensor& hcount,
+                       const Tensor& hweight, const Tensor& vstart, const Tensor& vcount,
+                       const Tensor& vweight, int64_t S, int64_t resize_h, int64_t resize_w,
+                       int64_t top, int64_t left, std::vector<double> mean,
+                       std::vector<double> stdv) {
+  TORCH_CHECK(img.is_cuda() && img.scalar_type() == at::kByte && img.is_contiguous() &&
+              img.dim() == 4 && img.size(3) == 3, "clip_preprocess: uint8 [T,H,W,3] expected");
+  for (const Tensor* tb : {&hstart, &hcount, &hweight, &vstart, &vcount, &vweight}) check_i32(*tb, "table");
+  const int64_t T = img.size(0), H = img.size(1), W = img.size(2);
+  TORCH_CHECK(mean.size() == 3 && stdv.size() == 3);
+  TORCH_CHECK(top >= 0 && left >= 0 && top + S <= resize_h && left + S <= resize_w);
+  const bool need_h = resize_w != W, need_v = resize_h != H;
+  TORCH_CHECK(!need_h || (hstart.numel() == resize_w && hcount.numel() == resize_w &&
+                          hweight.dim() == 2 && hweight.size(0) == resize_w));
+  TORCH_CHECK(!need_v || (vstart.numel() == resize_h && vcount.numel() == resize_h &&
+                          vweight.dim() == 2 && vweight.size(0) == resize_h));
+  Tensor out = at::empty({T, 3, S, S}, img.options().dtype(at::kBFloat16));
+  float m[3] = {(float)mean[0], (float)mean[1], (float)mean[2]};
+  float sd[3] = {(float)stdv[0], (float)stdv[1], (float)stdv[2]};
+  evgpt::launch_clip_preproc(img.data_ptr<uint8_t>(), bptr_mut(out), hstart.data_ptr<int>(),
+                             hcount.data_ptr<int>(), hweight.data_ptr<int>(),
+                             vstart.data_ptr<int>(), vcount.data_ptr<int>(),
+                             vweight.data_ptr<int>(), (int)T, (int)H, (int)W, (int)S,
+                             (int)resize_h, (int)resize_w, (int)top, (int)left,
+                             need_h ? (int)hweight.size(1) : 1, need_v ? (int)vweight.size(1) : 1,
+                             m, sd, cur_stream());
+  return out;
+}
+
+// ---------------------------------------------------------- speculative decode
+void verify_accept(const Tensor& pval, const Tensor& pidx, const Tensor& draft, int64_t G,
+                   const Tensor& out_tokens, const Tensor& step, const Tensor& pos,
+                   const Tensor& done, const Tensor& cur_token, const Tensor& result, int64_t eos,
+                   const Tensor& embed, const Tensor& x) {
+  check_f32(pval, "pval"); check_i32(pidx, "pidx"); check_i32(draft, "draft");
+  check_i32(out_tokens, "out_tokens"); check_i32(step, "step"); check_i32(pos, "pos");
+  check_i32(done, "done"); check_i32(cur_token, "cur_token"); check_i32(result, "result");
+  check_bf16(embed, "embed"); check_bf16(x, "x");
+  TORCH_CHECK(G >= 0 && G + 1 <= 64, "verify_accept: at most 63 draft tokens");
+  TORCH_CHECK(pval.dim() == 2 && pval.size(0) >= G + 1 && pidx.sizes() == pval.sizes());
+  TORCH_CHECK(draft.numel() >= G && result.numel() >= 3);
+  const int64_t H = embed.size(1);
+  TORCH_CHECK(x.numel() >= H && H % 8 == 0);
+  evgpt::launch_verify_accept(pval.data_ptr<float>(), pidx.data_ptr<int>(), (int)pval.size(1),
+                              draft.data_ptr<int>(), (int)G, out_tokens.data_ptr<int>(),
+                              (int)out_tokens.size(-1), step.data_ptr<int>(), pos.data_ptr<int>(),
+                              done.data_ptr<int>(), cur_token.data_ptr<int>(),
+                              result.data_ptr<int>(), (int)eos, bptr(embed), bptr_mut(x), (int)H,
+                              (int)embed.size(0), cur_stream());
+}
+
+void sample_top_p(const Tensor& logits, const Tensor& out, double temperature, double top_p,
+                  int64_t seed, const Tensor& step) {
+  check_f32(logits, "logits"); check_i32(out, "out"); check_i32(step, "step");
+  TORCH_CHECK(logits.dim() == 2 && logits.size(1) <= 40960 && temperature > 0);
+  const int64_t B = logits.size(0);
+  TORCH_CHECK(out.numel() >= B && step.numel() >= B);
+  evgpt::launch_sample_top_p(logits.data_ptr<float>(), out.data_ptr<int>(), (int)B,
+                             (int)logits.size(1), (float)temperature, (float)top_p,
+                             (unsigned long long)seed, step.data_ptr<int>(), cur_stream());
 }
 
 }  // namespace
@@ -370,5 +485,11 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("logits_partials(int N) -> int", &logits_partials);
   m.def("decode_logits(Tensor w, Tensor x, Tensor? norm_w, float eps, Tensor(a!)? logits, Tensor(b!) part_val, Tensor(c!) part_idx) -> ()", &decode_logits);
   m.def("commit_token(Tensor part_val, Tensor part_idx, int n_part, Tensor? sampled, Tensor embed, Tensor(a!) x, Tensor(b!) out_tokens, Tensor(c!) step, Tensor(d!) pos, Tensor(e!) done, Tensor(f!) cur_token, int eos) -> ()", &commit_token);
+  m.def("linear_argmax_partials(Tensor x, Tensor w, Tensor? bias) -> (Tensor, Tensor)", &linear_argmax_partials);
+  m.def("event_raster(Tensor x, Tensor y, Tensor p, int n_slices, int H, int W, int mode) -> Tensor", &event_raster);
+  m.def("event_voxel(Tensor x, Tensor y, Tensor p, Tensor t, int t0, int span, int bins, int H, int W, bool signed_mode, bool by_count) -> (Tensor, Tensor)", &event_voxel);
+  m.def("clip_preprocess(Tensor img, Tensor hstart, Tensor hcount, Tensor hweight, Tensor vstart, Tensor vcount, Tensor vweight, int S, int resize_h, int resize_w, int top, int left, float[] mean, float[] stdv) -> Tensor", &clip_preprocess);
+  m.def("verify_accept(Tensor pval, Tensor pidx, Tensor draft, int G, Tensor(a!) out_tokens, Tensor(b!) step, Tensor(c!) pos, Tensor(d!) done, Tensor(e!) cur_token, Tensor(f!) result, int eos, Tensor embed, Tensor(g!) x) -> ()", &verify_accept);
+  m.def("sample_top_p(Tensor logits, Tensor(a!) out, float temperature, float top_p, int seed, Tensor step) -> ()", &sample_top_p);
   m.def("prefill_rope_kv(Tensor qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos0, int Hq, int Hkv, int D) -> ()", &prefill_rope_kv);
 }

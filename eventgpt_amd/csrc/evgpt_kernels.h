@@ -24,9 +24,31 @@ void launch_gemv_logits(const bf16_t* W, const bf16_t* x, const bf16_t* norm_w, 
                         hipStream_t st);
 
 // ---- gemm.hip
+int gemm_argmax_partials(int M, int N);
 void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,
                       const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
-                      hipStream_t st);
+                      float* amax_val, int* amax_idx, hipStream_t st);
+
+// ---- event_ops.hip
+void launch_event_raster(const int* x, const int* y, const int* p, int n_events, int n_slices,
+                         int H, int W, int* keys, unsigned char* img, int mode, hipStream_t st);
+void launch_event_voxel(const int* x, const int* y, const int* p, const long long* t, int n_events,
+                        long long t0, long long span, int bins, int H, int W, int* out_hist,
+                        float* out_vox, int signed_mode, int by_count, hipStream_t st);
+void launch_clip_preproc(const unsigned char* img, bf16_t* out, const int* hstart,
+                         const int* hcount, const int* hweight, const int* vstart,
+                         const int* vcount, const int* vweight, int T, int H, int W, int S,
+                         int resize_h, int resize_w, int top, int left, int ksh, int ksv,
+                         const float* mean, const float* stdv, hipStream_t st);
+
+// ---- sd.hip
+void launch_verify_accept(const float* pval, const int* pidx, int n_part, const int* draft, int G,
+                          int* out_tokens, int max_out, int* step, int* pos, int* done,
+                          int* cur_token, int* result, int eos, const bf16_t* embed, bf16_t* x,
+                          int H, int vocab, hipStream_t st);
+void launch_sample_top_p(const float* logits, int* out, int B, int V, float temperature,
+                         float top_p, unsigned long long seed, const int* step,
+                         hipStream_t st);
 
 // ---- elementwise.hip
 void launch_rmsnorm(const bf16_t* x, const bf16_t* res, const bf16_t* w, bf16_t* y,
@@ -45,7 +67,7 @@ void launch_argmax_rows_bf16(const bf16_t* x, long long* out, int rows, int N, h
 void launch_commit_token(const float* part_val, const int* part_idx, int n_part,
                          const int* sampled, const bf16_t* embed, bf16_t* x, int* out_tokens,
                          int max_out, int* step, int* pos, int* done, int* cur_token, int eos,
-                         int B, int H, hipStream_t st);
+                         int B, int H, int vocab, hipStream_t st);
 
 // ---- attn_decode.hip
 void launch_attn_decode(const bf16_t* q, const bf16_t* k_cache, const bf16_t* v_cache,

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void commit_token_kernel(
     const float* __restrict__ part_val, const int* __restrict__ part_idx, int n_part,
     const int* __restrict__ sampled, const bf16_t* __restrict__ embed, bf16_t* __restrict__ x,
     int* __restrict__ out_tokens, int max_out, int* __restrict__ step, int* __restrict__ pos,
-    int* __restrict__ done, int* __restrict__ cur_token, int eos, int H) {
+    int* __restrict__ done, int* __restrict__ cur_token, int eos, int H, int vocab) {
   __shared__ float sv[4];
   __shared__ int si[4];
   __shared__ int tok_s;
@@ -355,7 +355,8 @@ __global__ __launch_bounds__(256) void commit_token_kernel(
     }
   }
   __syncthreads();
-  const int tok = tok_s;
+  int tok = tok_s;
+  if (tok < 0 || tok >= vocab) tok = 0;  // all-NaN logits must not turn into a wild gather
   const int st = step[b];
   if (threadIdx.x == 0) {
     if (st < max_out) out_tokens[b * max_out + st] = tok;
@@ -377,9 +378,9 @@ __global__ __launch_bounds__(256) void commit_token_kernel(
 void launch_commit_token(const float* part_val, const int* part_idx, int n_part,
                          const int* sampled, const bf16_t* embed, bf16_t* x, int* out_tokens,
                          int max_out, int* step, int* pos, int* done, int* cur_token, int eos,
-                         int B, int H, hipStream_t st) {
+                         int B, int H, int vocab, hipStream_t st) {
   hipLaunchKernelGGL(commit_token_kernel, dim3(B), dim3(256), 0, st, part_val, part_idx, n_part,
-                     sampled, embed, x, out_tokens, max_out, step, pos, done, cur_token, eos, H);
+                     sampled, embed, x, out_tokens, max_out, step, pos, done, cur_token, eos, H, vocab);
 }
 
 }  // namespace evgpt

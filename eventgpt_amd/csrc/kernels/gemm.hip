@@ -41,6 +41,11 @@ struct GemmParams {
   const bf16_t* res;   // [M][ldc] or null (may alias C)
   float* Cf;           // optional fp32 output [M][ldc] (C may be null)
   int M, N, K, lda, ldw, ldc, act;
+  // optional row-argmax partials: [M][n_part] (value, index), n_part = tiles_n * WGN.
+  // Values are the bf16-rounded outputs, so the result equals argmax over a
+  // materialised bf16 C without ever writing it.
+  float* amax_val;
+  int* amax_idx;
 };
 
 template <int BM, int BN, int WGM, int WGN>
@@ -128,7 +133,34 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wr * WM + i * 16 + frow;
-    if (m >= p.M) continue;
+    if (p.amax_val) {
+      // row max over this wave's WN columns: in-lane over j and r, then across the
+      // 4 lanes (fq) that share the row
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wc * WN + j * 16 + fq * 4 + r;
+          float v = acc[i][j][r];
+          if (p.bias && n < p.N) v += bf16_to_f32(p.bias[n]);
+          v = bf16_to_f32(f32_to_bf16(v));
+          if (n < p.N && (v > bv || (v == bv && n < bi))) { bv = v; bi = n; }
+        }
+#pragma unroll
+      for (int off = 16; off < 64; off <<= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (fq == 0 && m < p.M) {
+        const int n_part = tiles_n * WGN;
+        p.amax_val[static_cast<size_t>(m) * n_part + tn * WGN + wc] = bv;
+        p.amax_idx[static_cast<size_t>(m) * n_part + tn * WGN + wc] = bi;
+      }
+    }
+    if (m >= p.M || (!p.C && !p.Cf)) continue;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wc * WN + j * 16 + fq * 4;
@@ -173,10 +205,16 @@ static void launch_cfg(const GemmParams& p, hipStream_t st) {
   hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN>), dim3(tiles), dim3(256), smem, st, p);
 }
 
+int gemm_argmax_partials(int M, int N) {
+  // must mirror the tile choice in launch_gemm_bf16
+  if (M <= 32) return ((N + 127) / 128) * 4;
+  return ((N + 127) / 128) * 2;
+}
+
 void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,
                       const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
-                      hipStream_t st) {
-  GemmParams p{A, W, C, bias, res, Cf, M, N, K, lda, ldw, ldc, act};
+                      float* amax_val, int* amax_idx, hipStream_t st) {
+  GemmParams p{A, W, C, bias, res, Cf, M, N, K, lda, ldw, ldc, act, amax_val, amax_idx};
   // Tile choice: fill 256 CUs.  Small M (prefill of a few hundred rows, verify
   // batches) uses shorter tiles so the grid is not a fraction of the chip.
   const long long t128 = static_cast<long long>((M + 127) / 128) * ((N + 127) / 128);

@@ -192,7 +192,10 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
           for (int r = 0; r < R; ++r) {
             if (row[r] < p.N) {
               const size_t o = static_cast<size_t>(b) * p.N + row[r];
-              const float v = bf16_to_f32(f32_to_bf16(acc[r][b])) + bf16_to_f32(p.res[o]);
+              float v = acc[r][b];
+              if (p.bias) v += bf16_to_f32(p.bias[row[r]]);
+              v = apply_act(v, p.act);
+              v = bf16_to_f32(f32_to_bf16(v)) + bf16_to_f32(p.res[o]);
               p.y[o] = f32_to_bf16(v);
             }
           }

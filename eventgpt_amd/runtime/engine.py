@@ -259,8 +259,11 @@ class GenerationEngine:
 
     # --------------------------------------------------------------- generate
     def _sample_and_commit(self, temperature: float, top_p: float, generator) -> None:
-        tok = ops.sample_top_p(self.logits, temperature, top_p, generator)
-        self.sampled.copy_(tok.to(torch.int32))
+        """Draw the next token on the device (bisection top-p kernel keyed by
+        ``(seed, step)``) and commit it; no host round trip."""
+        seed = int(generator.initial_seed()) if generator is not None else 0
+        self.raw.sample_top_p(self.logits, self.sampled, float(temperature), float(top_p),
+                              seed & 0x7FFFFFFFFFFFFFFF, self.step)
         self._commit_sampled()
 
     @torch.no_grad()
