@@ -258,7 +258,7 @@ void decode_attn(const Tensor& q, const Tensor& k_cache, const Tensor& v_cache, 
   const int64_t Hq = q.numel() / (B * D);
   TORCH_CHECK(Hq * B * D == q.numel() && Hq % Hkv == 0 && out.numel() == q.numel());
   TORCH_CHECK(part_o.numel() >= B * Hq * nsplit * D && part_ml.numel() >= B * Hq * nsplit * 2);
-  TORCH_CHECK(pos.numel() == B && nsplit >= 1);
+  TORCH_CHECK(pos.numel() == B && nsplit >= 1 && nsplit <= 16, "decode_attn: 1..16 splits");
   evgpt::launch_attn_decode(bptr(q), bptr(k_cache), bptr(v_cache), bptr_mut(out),
                             part_o.data_ptr<float>(), part_ml.data_ptr<float>(),
                             pos.data_ptr<int>(), (int)B, (int)Hq, (int)Hkv, (int)D, (int)Lmax,
@@ -432,6 +432,33 @@ Tensor clip_preprocess(const Tensor& img, const Tensor& hstart, const Tensor& hc
   return out;
 }
 
+// pixels [T,C,S,S] -> patch rows [T*G*G, Kp] (zero padded to a multiple of 64)
+Tensor patchify(const Tensor& px, int64_t P) {
+  check_bf16(px, "pixels");
+  TORCH_CHECK(px.dim() == 4 && px.size(2) == px.size(3) && px.size(2) % P == 0);
+  const int64_t T = px.size(0), C = px.size(1), S = px.size(2), G = S / P;
+  const int64_t Kp = ((C * P * P + 63) / 64) * 64;
+  Tensor out = at::empty({T * G * G, Kp}, px.options());
+  evgpt::launch_patchify(bptr(px), bptr_mut(out), (int)T, (int)C, (int)S, (int)P, (int)Kp,
+                         cur_stream());
+  return out;
+}
+
+// tok [T,N-1,H] + cls/pos embeddings + pre-LayerNorm -> [T,N,H]
+Tensor vit_embed_ln(const Tensor& tok, const Tensor& cls, const Tensor& pos, const Tensor& w,
+                    const Tensor& b, double eps) {
+  check_bf16(tok, "tok"); check_bf16(cls, "cls"); check_bf16(pos, "pos"); check_bf16(w, "w");
+  check_bf16(b, "b");
+  TORCH_CHECK(tok.dim() == 3 && pos.dim() == 2);
+  const int64_t T = tok.size(0), N = tok.size(1) + 1, H = tok.size(2);
+  TORCH_CHECK(pos.size(0) == N && pos.size(1) == H && cls.numel() == H && w.numel() == H &&
+              b.numel() == H && H <= 2048, "vit_embed_ln: shape mismatch (hidden <= 2048)");
+  Tensor out = at::empty({T, N, H}, tok.options());
+  evgpt::launch_vit_embed_ln(bptr(tok), bptr(cls), bptr(pos), bptr(w), bptr(b), bptr_mut(out),
+                             (int)T, (int)N, (int)H, (float)eps, cur_stream());
+  return out;
+}
+
 // ---------------------------------------------------------- speculative decode
 void verify_accept(const Tensor& pval, const Tensor& pidx, const Tensor& draft, int64_t G,
                    const Tensor& out_tokens, const Tensor& step, const Tensor& pos,
@@ -489,6 +516,8 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("event_raster(Tensor x, Tensor y, Tensor p, int n_slices, int H, int W, int mode) -> Tensor", &event_raster);
   m.def("event_voxel(Tensor x, Tensor y, Tensor p, Tensor t, int t0, int span, int bins, int H, int W, bool signed_mode, bool by_count) -> (Tensor, Tensor)", &event_voxel);
   m.def("clip_preprocess(Tensor img, Tensor hstart, Tensor hcount, Tensor hweight, Tensor vstart, Tensor vcount, Tensor vweight, int S, int resize_h, int resize_w, int top, int left, float[] mean, float[] stdv) -> Tensor", &clip_preprocess);
+  m.def("patchify(Tensor px, int P) -> Tensor", &patchify);
+  m.def("vit_embed_ln(Tensor tok, Tensor cls, Tensor pos, Tensor w, Tensor b, float eps) -> Tensor", &vit_embed_ln);
   m.def("verify_accept(Tensor pval, Tensor pidx, Tensor draft, int G, Tensor(a!) out_tokens, Tensor(b!) step, Tensor(c!) pos, Tensor(d!) done, Tensor(e!) cur_token, Tensor(f!) result, int eos, Tensor embed, Tensor(g!) x) -> ()", &verify_accept);
   m.def("sample_top_p(Tensor logits, Tensor(a!) out, float temperature, float top_p, int seed, Tensor step) -> ()", &sample_top_p);
   m.def("prefill_rope_kv(Tensor qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos0, int Hq, int Hkv, int D) -> ()", &prefill_rope_kv);

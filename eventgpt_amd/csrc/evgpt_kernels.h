@@ -69,6 +69,12 @@ void launch_commit_token(const float* part_val, const int* part_idx, int n_part,
                          int max_out, int* step, int* pos, int* done, int* cur_token, int eos,
                          int B, int H, int vocab, hipStream_t st);
 
+void launch_patchify(const bf16_t* px, bf16_t* out, int T, int C, int S, int P, int Kp,
+                     hipStream_t st);
+void launch_vit_embed_ln(const bf16_t* tok, const bf16_t* cls, const bf16_t* pos, const bf16_t* w,
+                         const bf16_t* b, bf16_t* out, int T, int N, int H, float eps,
+                         hipStream_t st);
+
 // ---- attn_decode.hip
 void launch_attn_decode(const bf16_t* q, const bf16_t* k_cache, const bf16_t* v_cache,
                         bf16_t* out, float* part_o, float* part_ml, const int* pos, int B, int Hq,

@@ -126,14 +126,26 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __r
                                                                 int nsplit) {
   const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
   const size_t base = (static_cast<size_t>(b) * Hq + h) * nsplit;
+  constexpr int MAXS = 16;
+  // issue every load before the first use: the kernel is a handful of dependent
+  // L2 round trips, so they must overlap
+  float ms[MAXS], ls[MAXS], os[MAXS];
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    const bool ok = s < nsplit;
+    ms[s] = ok ? part_ml[(base + s) * 2] : -INFINITY;
+    ls[s] = ok ? part_ml[(base + s) * 2 + 1] : 0.f;
+    os[s] = ok ? part_o[(base + s) * D + d] : 0.f;
+  }
   float mm = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, part_ml[(base + s) * 2]);
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) mm = fmaxf(mm, ms[s]);
   float ll = 0.f, oo = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float ms = part_ml[(base + s) * 2];
-    const float c = (ms == -INFINITY) ? 0.f : __expf(ms - mm);
-    ll += part_ml[(base + s) * 2 + 1] * c;
-    oo += part_o[(base + s) * D + d] * c;
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    const float c = (ms[s] == -INFINITY) ? 0.f : __expf(ms[s] - mm);
+    ll += ls[s] * c;
+    oo += os[s] * c;
   }
   out[(static_cast<size_t>(b) * Hq + h) * D + d] = f32_to_bf16(oo / ll);
 }

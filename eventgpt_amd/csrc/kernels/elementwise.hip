@@ -384,3 +384,72 @@ void launch_commit_token(const float* part_val, const int* part_idx, int n_part,
 }
 
 }  // namespace evgpt
+
+namespace evgpt {
+
+// ------------------------------------------------------------- ViT front end
+// patchify: pixels [T][C][S][S] bf16 -> rows [T*G*G][Kp] in the conv weight's
+// (c, ph, pw) order, zero-padded from C*P*P to Kp (a multiple of 64) so the
+// patch embedding is one MFMA GEMM.  One thread per output element pair.
+__global__ __launch_bounds__(256) void patchify_kernel(const bf16_t* __restrict__ px,
+                                                       bf16_t* __restrict__ out, int T, int C,
+                                                       int S, int P, int Kp) {
+  const int G = S / P, K = C * P * P;
+  const long long total = static_cast<long long>(T) * G * G * Kp;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const int k = static_cast<int>(i % Kp);
+    const long long row = i / Kp;
+    bf16_t v = 0;
+    if (k < K) {
+      const int t = static_cast<int>(row / (G * G)), g = static_cast<int>(row % (G * G));
+      const int gy = g / G, gx = g % G;
+      const int c = k / (P * P), py = (k % (P * P)) / P, pxx = k % P;
+      v = px[((static_cast<size_t>(t) * C + c) * S + gy * P + py) * S + gx * P + pxx];
+    }
+    out[i] = v;
+  }
+}
+
+void launch_patchify(const bf16_t* px, bf16_t* out, int T, int C, int S, int P, int Kp,
+                     hipStream_t st) {
+  const long long total = static_cast<long long>(T) * (S / P) * (S / P) * Kp;
+  int blocks = static_cast<int>((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(patchify_kernel, dim3(blocks), dim3(256), 0, st, px, out, T, C, S, P, Kp);
+}
+
+// embed + pre-LayerNorm: row (t, n) = LN( n == 0 ? cls + pos[0] : tok[t][n-1] + pos[n] ).
+// tok: [T][N-1][H] (patch GEMM output), pos: [N][H], out: [T][N][H].
+__global__ __launch_bounds__(256) void vit_embed_ln_kernel(
+    const bf16_t* __restrict__ tok, const bf16_t* __restrict__ cls, const bf16_t* __restrict__ pos,
+    const bf16_t* __restrict__ w, const bf16_t* __restrict__ b, bf16_t* __restrict__ out, int N,
+    int H, float eps) {
+  __shared__ float red[16];
+  __shared__ __attribute__((aligned(16))) float rowbuf[2048];
+  const int t = blockIdx.x / N, n = blockIdx.x % N;
+  const bf16_t* src = n == 0 ? cls : tok + (static_cast<size_t>(t) * (N - 1) + (n - 1)) * H;
+  const bf16_t* pp = pos + static_cast<size_t>(n) * H;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < H; i += 256) {
+    // sum is rounded to bf16 like the separate embedding add it replaces
+    const float v = bf16_to_f32(f32_to_bf16(bf16_to_f32(src[i]) + bf16_to_f32(pp[i])));
+    rowbuf[i] = v;
+    s += v;
+  }
+  const float mean = block_sum(s, red) / static_cast<float>(H);
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < H; i += 256) { const float d = rowbuf[i] - mean; ss += d * d; }
+  const float rstd = rsqrtf(block_sum(ss, red) / static_cast<float>(H) + eps);
+  bf16_t* dst = out + static_cast<size_t>(blockIdx.x) * H;
+  for (int i = threadIdx.x; i < H; i += 256)
+    dst[i] = f32_to_bf16((rowbuf[i] - mean) * rstd * bf16_to_f32(w[i]) + bf16_to_f32(b[i]));
+}
+
+void launch_vit_embed_ln(const bf16_t* tok, const bf16_t* cls, const bf16_t* pos, const bf16_t* w,
+                         const bf16_t* b, bf16_t* out, int T, int N, int H, float eps,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(vit_embed_ln_kernel, dim3(T * N), dim3(256), 0, st, tok, cls, pos, w, b, out,
+                     N, H, eps);
+}
+
+}  // namespace evgpt

@@ -3,17 +3,23 @@
 //   y[b][n] = epilogue( sum_k W[n][k] * prologue(x)[b][k] )
 //
 // Regime: one token per sequence reads every weight exactly once (13.5 GB per
-// token for a 7B model), so these kernels are pure HBM streaming.  Design:
+// token for a 7B model), so these kernels are pure HBM streaming and what
+// matters is bytes in flight per CU.  Design:
 //   * weights go straight from HBM to VGPRs with non-temporal 16-byte loads
 //     (no LDS round trip: a weight byte is used by exactly one wave);
-//   * the activation vector (8-22 KB) is staged once per block in LDS, with the
-//     RMSNorm of the producing layer folded into that staging pass, so norm and
-//     projection are one launch;
-//   * one wave owns R=4 output rows at a time and keeps 16 loads (16 KB) in
-//     flight; v_dot2c_f32_bf16 does the MACs without bf16->f32 unpacking;
-//   * epilogues fuse what would otherwise be separate launches: residual add,
-//     SwiGLU (gate/up row pairs), RoPE + KV-cache append (q/k row pairs j,j+64),
-//     fp32 logits + per-block argmax partials.
+//   * a *unit* of R=4 output rows is shared by KS waves that each stream 1/KS of
+//     the K range and combine through LDS.  KS is chosen per shape so that every
+//     launch puts >= 24 waves on each of the 256 CUs: a 4096-row matrix is only
+//     1024 units, which at one wave per unit is 4 waves per CU and measured
+//     2.9 TB/s; with KS=4 the same matrix keeps 16+ waves per CU streaming;
+//   * activations: with a fused RMSNorm the block stages the normalised vector
+//     in LDS once (norm and projection are one launch); without a norm each lane
+//     reads its x chunk straight from L2 — no barrier before the first weight
+//     load;
+//   * v_dot2c_f32_bf16 does the MACs without bf16->f32 unpacking;
+//   * epilogues fuse what would otherwise be separate launches: bias/act,
+//     residual add, SwiGLU (gate/up row pairs), RoPE + KV-cache append (q/k row
+//     pairs j, j+D/2), fp32 logits + per-block argmax partials.
 // Positions / cache lengths are read from device memory so a captured graph can
 // be replayed for every token.
 #include "common.h"
@@ -33,7 +39,7 @@ struct GemvParams {
   // E_STORE / E_RESIDUAL / E_SWIGLU
   bf16_t* y;             // [B][N_out]
   const bf16_t* res;     // [B][N]        (E_RESIDUAL; may alias y)
-  const bf16_t* bias;    // [N] or null   (E_STORE)
+  const bf16_t* bias;    // [N] or null
   int act;
   // E_QKV_ROPE
   bf16_t* q_out;         // [B][Hq*D]
@@ -49,7 +55,7 @@ struct GemvParams {
   int* part_idx;
 };
 
-constexpr int R = 4;           // rows per wave
+constexpr int R = 4;           // rows per unit
 constexpr int GEMV_WAVES = 4;  // waves per block
 
 template <int E>
@@ -75,16 +81,23 @@ __device__ __forceinline__ void unit_rows(const GemvParams& p, int u, int (&row)
   }
 }
 
-template <int B, int P, int E>
+template <int B, int P, int E, int KS>
 __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
+  static_assert(KS == 1 || KS == 2 || KS == 4, "KS waves per unit");
+  static_assert(E != E_LOGITS || KS == 1, "logits epilogue runs one wave per unit");
+  constexpr int UPB = GEMV_WAVES / KS;  // units per block iteration
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);  // [B][K/8] 16-byte chunks
+  // LDS carve: [partials: GEMV_WAVES*R*B floats][argmax scratch][x image (P_RMSNORM)]
+  float* part = reinterpret_cast<float*>(smem);
+  constexpr int PART_BYTES = ((GEMV_WAVES * R * B * 4 + 15) / 16) * 16;
+  float* red = reinterpret_cast<float*>(smem + PART_BYTES);          // 16 floats
+  u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem + PART_BYTES + 64);  // [B][K/8]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ks = wid % KS, ub_slot = wid / KS;
   const int nchunk = p.K >> 3;
 
-  // ---------------- prologue: stage (and normalise) x into LDS ----------------
+  // ---------------- prologue: normalise x into LDS (fused RMSNorm) ----------------
   if constexpr (P == P_RMSNORM) {
-    float* red = reinterpret_cast<float*>(smem + static_cast<size_t>(B) * nchunk * 16);
 #pragma unroll
     for (int b = 0; b < B; ++b) {
       float ss = 0.f;
@@ -112,16 +125,16 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
         xs[b * nchunk + c] = o;
       }
     }
-  } else {
-#pragma unroll
-    for (int b = 0; b < B; ++b)
-      for (int c = tid; c < nchunk; c += blockDim.x)
-        xs[b * nchunk + c] = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+    __syncthreads();
   }
-  __syncthreads();
 
-  // ------------------------------ main loop ------------------------------
+  // this wave's slice of the K range, in 16-byte chunks
+  const int cper = (nchunk + KS - 1) / KS;
+  const int c_begin = ks * cper;
+  const int c_end = min(c_begin + cper, nchunk);
+
   const int n_units = (p.N + R - 1) / R;
+  const int n_ub = (n_units + UPB - 1) / UPB;
   float best_val[B];
   int best_idx[B];
   if constexpr (E == E_LOGITS) {
@@ -129,9 +142,12 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
     for (int b = 0; b < B; ++b) { best_val[b] = -INFINITY; best_idx[b] = 0; }
   }
 
-  for (int u = blockIdx.x * GEMV_WAVES + wid; u < n_units; u += gridDim.x * GEMV_WAVES) {
+  // block-uniform trip count: the partial-sum exchange below contains a barrier
+  for (int ub = blockIdx.x; ub < n_ub; ub += gridDim.x) {
+    const int u = ub * UPB + ub_slot;
+    const bool unit_ok = u < n_units;
     int row[R];
-    unit_rows<E>(p, u, row);
+    unit_rows<E>(p, unit_ok ? u : n_units - 1, row);
     const bf16_t* wp[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -145,13 +161,15 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
       for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
 
 #pragma unroll 4
-    for (int c = lane; c < nchunk; c += 64) {
+    for (int c = c_begin + lane; c < c_end; c += 64) {
       u32x4_t wv[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) wv[r] = load_stream16(wp[r] + c * 8);
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        const u32x4_t xv = xs[b * nchunk + c];
+        u32x4_t xv;
+        if constexpr (P == P_RMSNORM) xv = xs[b * nchunk + c];
+        else xv = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r][b] = dot8_bf16(wv[r], xv, acc[r][b]);
       }
@@ -160,6 +178,27 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int b = 0; b < B; ++b) acc[r][b] = wave_sum(acc[r][b]);
+
+    if constexpr (KS > 1) {
+      // combine the KS partial sums of each unit through LDS; wave ks==0 finishes
+      __syncthreads();  // previous iteration's readers are done with `part`
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int b = 0; b < B; ++b) part[(wid * R + r) * B + b] = acc[r][b];
+      }
+      __syncthreads();
+      if (ks == 0) {
+#pragma unroll
+        for (int k2 = 1; k2 < KS; ++k2)
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int b = 0; b < B; ++b) acc[r][b] += part[((wid + k2) * R + r) * B + b];
+      }
+    }
+    if (!unit_ok || ks != 0) continue;
 
     // ------------------------------ epilogues ------------------------------
     if constexpr (E == E_LOGITS) {
@@ -245,47 +284,73 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
 
   if constexpr (E == E_LOGITS) {
     // block-level argmax partial: (value, lowest index on ties)
-    __shared__ float sv[GEMV_WAVES][B];
-    __shared__ int si[GEMV_WAVES][B];
+    float* sv = part;                                  // [GEMV_WAVES][B]
+    int* si = reinterpret_cast<int*>(part) + GEMV_WAVES * B;
+    __syncthreads();
     if (lane == 0) {
 #pragma unroll
-      for (int b = 0; b < B; ++b) { sv[wid][b] = best_val[b]; si[wid][b] = best_idx[b]; }
+      for (int b = 0; b < B; ++b) { sv[wid * B + b] = best_val[b]; si[wid * B + b] = best_idx[b]; }
     }
     __syncthreads();
     if (tid < B) {
-      float bv = sv[0][tid];
-      int bi = si[0][tid];
+      float bv = sv[tid];
+      int bi = si[tid];
       for (int w = 1; w < GEMV_WAVES; ++w)
-        if (sv[w][tid] > bv || (sv[w][tid] == bv && si[w][tid] < bi)) { bv = sv[w][tid]; bi = si[w][tid]; }
+        if (sv[w * B + tid] > bv || (sv[w * B + tid] == bv && si[w * B + tid] < bi)) {
+          bv = sv[w * B + tid]; bi = si[w * B + tid];
+        }
       p.part_val[tid * gridDim.x + blockIdx.x] = bv;
       p.part_idx[tid * gridDim.x + blockIdx.x] = bi;
     }
   }
 }
 
-template <int P, int E>
-static void launch_b(const GemvParams& p, int B, int grid, hipStream_t st) {
-  const size_t smem = static_cast<size_t>(B) * (p.K / 8) * 16 + (P == P_RMSNORM ? 64 : 0);
-  dim3 g(grid), b(GEMV_WAVES * 64);
-  switch (B) {
-    case 1: hipLaunchKernelGGL((gemv_kernel<1, P, E>), g, b, smem, st, p); break;
-    case 2: hipLaunchKernelGGL((gemv_kernel<2, P, E>), g, b, smem, st, p); break;
-    case 3: hipLaunchKernelGGL((gemv_kernel<3, P, E>), g, b, smem, st, p); break;
-    case 4: hipLaunchKernelGGL((gemv_kernel<4, P, E>), g, b, smem, st, p); break;
-    default: break;
-  }
+// waves-per-unit so that the launch has >= ~6000 waves (24 per CU)
+static int pick_ks(int N) {
+  const int units = (N + R - 1) / R;
+  if (units >= 6000) return 1;
+  if (units >= 3000) return 2;
+  return 4;
 }
 
-static int gemv_grid(int N) {
+static int gemv_grid(int N, int ks) {
   const int units = (N + R - 1) / R;
-  int blocks = (units + GEMV_WAVES - 1) / GEMV_WAVES;
+  const int upb = GEMV_WAVES / ks;
+  int blocks = (units + upb - 1) / upb;
   const int cap = 256 * 8;  // 8 blocks per CU; the rest is a grid-stride loop
   return blocks < cap ? blocks : cap;
 }
 
+template <int P, int E, int KS>
+static void launch_bk(const GemvParams& p, int B, hipStream_t st) {
+  const size_t part = ((GEMV_WAVES * R * B * 4 + 15) / 16) * 16;
+  const size_t smem = part + 64 + (P == P_RMSNORM ? static_cast<size_t>(B) * (p.K / 8) * 16 : 0);
+  dim3 g(gemv_grid(p.N, KS)), b(GEMV_WAVES * 64);
+  switch (B) {
+    case 1: hipLaunchKernelGGL((gemv_kernel<1, P, E, KS>), g, b, smem, st, p); break;
+    case 2: hipLaunchKernelGGL((gemv_kernel<2, P, E, KS>), g, b, smem, st, p); break;
+    case 3: hipLaunchKernelGGL((gemv_kernel<3, P, E, KS>), g, b, smem, st, p); break;
+    case 4: hipLaunchKernelGGL((gemv_kernel<4, P, E, KS>), g, b, smem, st, p); break;
+    default: break;
+  }
+}
+
+template <int P, int E>
+static void launch_b(const GemvParams& p, int B, hipStream_t st) {
+  if constexpr (E == E_LOGITS) {
+    launch_bk<P, E, 1>(p, B, st);
+  } else {
+    switch (pick_ks(p.N)) {
+      case 1: launch_bk<P, E, 1>(p, B, st); break;
+      case 2: launch_bk<P, E, 2>(p, B, st); break;
+      default: launch_bk<P, E, 4>(p, B, st); break;
+    }
+  }
+}
+
 int gemv_max_batch() { return 4; }
 
-int gemv_logits_grid(int N) { return gemv_grid(N); }
+int gemv_logits_grid(int N) { return gemv_grid(N, 1); }
 
 void launch_gemv(const bf16_t* W, const bf16_t* x, bf16_t* y, const bf16_t* bias,
                  const bf16_t* res, const bf16_t* norm_w, float eps, int act, int B, int N,
@@ -293,13 +358,12 @@ void launch_gemv(const bf16_t* W, const bf16_t* x, bf16_t* y, const bf16_t* bias
   GemvParams p{};
   p.W = W; p.x = x; p.y = y; p.bias = bias; p.res = res; p.norm_w = norm_w; p.eps = eps;
   p.act = act; p.N = N; p.K = K;
-  const int grid = gemv_grid(N);
   if (res) {
-    if (norm_w) launch_b<P_RMSNORM, E_RESIDUAL>(p, B, grid, st);
-    else launch_b<P_NONE, E_RESIDUAL>(p, B, grid, st);
+    if (norm_w) launch_b<P_RMSNORM, E_RESIDUAL>(p, B, st);
+    else launch_b<P_NONE, E_RESIDUAL>(p, B, st);
   } else {
-    if (norm_w) launch_b<P_RMSNORM, E_STORE>(p, B, grid, st);
-    else launch_b<P_NONE, E_STORE>(p, B, grid, st);
+    if (norm_w) launch_b<P_RMSNORM, E_STORE>(p, B, st);
+    else launch_b<P_NONE, E_STORE>(p, B, st);
   }
 }
 
@@ -308,9 +372,8 @@ void launch_gemv_swiglu(const bf16_t* W_gate_up, const bf16_t* x, bf16_t* y,
                         hipStream_t st) {
   GemvParams p{};
   p.W = W_gate_up; p.x = x; p.y = y; p.norm_w = norm_w; p.eps = eps; p.N = 2 * inter; p.K = K;
-  const int grid = gemv_grid(2 * inter);
-  if (norm_w) launch_b<P_RMSNORM, E_SWIGLU>(p, B, grid, st);
-  else launch_b<P_NONE, E_SWIGLU>(p, B, grid, st);
+  if (norm_w) launch_b<P_RMSNORM, E_SWIGLU>(p, B, st);
+  else launch_b<P_NONE, E_SWIGLU>(p, B, st);
 }
 
 void launch_gemv_qkv_rope(const bf16_t* W_qkv, const bf16_t* x, const bf16_t* norm_w, float eps,
@@ -323,9 +386,8 @@ void launch_gemv_qkv_rope(const bf16_t* W_qkv, const bf16_t* x, const bf16_t* no
   p.q_out = q_out; p.k_cache = k_cache; p.v_cache = v_cache; p.cos_tab = cos_tab;
   p.sin_tab = sin_tab; p.pos = pos; p.n_q_heads = n_q_heads; p.n_kv_heads = n_kv_heads;
   p.head_dim = head_dim; p.l_max = l_max;
-  const int grid = gemv_grid(p.N);
-  if (norm_w) launch_b<P_RMSNORM, E_QKV_ROPE>(p, B, grid, st);
-  else launch_b<P_NONE, E_QKV_ROPE>(p, B, grid, st);
+  if (norm_w) launch_b<P_RMSNORM, E_QKV_ROPE>(p, B, st);
+  else launch_b<P_NONE, E_QKV_ROPE>(p, B, st);
 }
 
 void launch_gemv_logits(const bf16_t* W, const bf16_t* x, const bf16_t* norm_w, float eps,
@@ -334,9 +396,8 @@ void launch_gemv_logits(const bf16_t* W, const bf16_t* x, const bf16_t* norm_w, 
   GemvParams p{};
   p.W = W; p.x = x; p.norm_w = norm_w; p.eps = eps; p.N = N; p.K = K;
   p.logits = logits; p.part_val = part_val; p.part_idx = part_idx;
-  const int grid = gemv_grid(N);
-  if (norm_w) launch_b<P_RMSNORM, E_LOGITS>(p, B, grid, st);
-  else launch_b<P_NONE, E_LOGITS>(p, B, grid, st);
+  if (norm_w) launch_b<P_RMSNORM, E_LOGITS>(p, B, st);
+  else launch_b<P_NONE, E_LOGITS>(p, B, st);
 }
 
 }  // namespace evgpt

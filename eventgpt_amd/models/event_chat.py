@@ -271,6 +271,8 @@ class EventChatModel(nn.Module):
     def encode_event_frames(self, frames: Sequence[torch.Tensor]) -> torch.Tensor:
         """All frames of one sample in one tower batch → pooled ``[T+S, hidden]``."""
         batch = torch.stack([f.to(self.device) for f in frames])
+        if batch.is_cuda and self.dtype == torch.bfloat16 and not torch.is_grad_enabled():
+            return self.vision_engine().encode(batch)
         feats = self.visval_encode(batch)
         if hasattr(self.get_model(), "feature_adaptor"):
             feats = self.get_model().feature_adaptor(feats)
@@ -491,6 +493,13 @@ class EventChatModel(nn.Module):
         return seq
 
     # ------------------------------------------------------------------- engine
+    def vision_engine(self, **kwargs):
+        """Graph-captured event tower bound to this model's weights."""
+        if getattr(self, "_vision_engine", None) is None:
+            from ..runtime.vision_engine import VisionEngine
+            self._vision_engine = VisionEngine(self, **kwargs)
+        return self._vision_engine
+
     def engine(self, **kwargs):
         """The serving engine bound to this model's weights (built on first use)."""
         if self._engine is None:

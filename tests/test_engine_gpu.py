@@ -87,3 +87,26 @@ def test_sampling_runs(model, dev):
     g = torch.Generator(device=dev).manual_seed(0)
     t = eng.generate(emb, 12, temperature=0.7, top_p=0.9, eos_token_id=-1, generator=g)
     assert t.shape == (12,) and int(t.min()) >= 0 and int(t.max()) < 1003
+
+
+def test_vision_engine_matches_module_path(dev):
+    from eventgpt_amd.models import ClipVisionConfig
+    cfg = EventChatConfig(vocab_size=1003, hidden_size=512, intermediate_size=1408,
+                          num_hidden_layers=1, num_attention_heads=4, mm_visual_tower="t",
+                          event_feature_adaptor=True)
+    cfg.vision_config = ClipVisionConfig(hidden_size=256, intermediate_size=512,
+                                         num_hidden_layers=3, num_attention_heads=4,
+                                         image_size=56, patch_size=14)
+    m = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=3)
+    frames = (torch.randn(5, 3, 56, 56, device=dev)).to(torch.bfloat16)
+    feats = m.get_model().feature_adaptor(m.visval_encode(frames))
+    from eventgpt_amd.models import get_spatio_temporal_features
+    want = get_spatio_temporal_features(feats)
+    got = m.vision_engine().encode(frames)
+    got2 = m.vision_engine().encode(frames)        # graph replay
+    assert got.shape == (5 + 17, 512)
+    assert torch.equal(got, got2)
+    err = (got.float() - want.float()).abs().max().item()
+    assert err < 0.06, err
+    one = m.vision_engine().encode(frames[:1])
+    assert one.shape == (1 + 17, 512)
