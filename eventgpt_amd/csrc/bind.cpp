@@ -109,10 +109,13 @@ Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bia
                        (int)act, (int)M, (int)N, (int)K, st);
   } else {
     TORCH_CHECK(K % 64 == 0, "linear: the MFMA GEMM needs K % 64 == 0 (pad the operands)");
+    const int sk = evgpt::gemm_splitk((int)M, (int)N, (int)K);
+    Tensor ws;
+    if (sk > 1) ws = at::empty({sk * M * N}, x.options().dtype(at::kFloat));
     evgpt::launch_gemm_bf16(bptr(x), bptr(w), out_f32 ? nullptr : bptr_mut(y),
                             out_f32 ? y.data_ptr<float>() : nullptr, bptr_opt(bias),
                             bptr_opt(res), (int)M, (int)N, (int)K, (int)K, (int)K, (int)N, (int)act,
-                            nullptr, nullptr, st);
+                            nullptr, nullptr, sk > 1 ? ws.data_ptr<float>() : nullptr, sk, st);
   }
   return y;
 }
@@ -364,9 +367,12 @@ std::tuple<Tensor, Tensor> linear_argmax_partials(const Tensor& x, const Tensor&
   Tensor idx = at::empty({M, P}, x.options().dtype(at::kInt));
   evgpt::launch_gemm_bf16(bptr(x), bptr(w), nullptr, nullptr, bptr_opt(bias), nullptr, (int)M,
                           (int)N, (int)K, (int)K, (int)K, (int)N, 0, val.data_ptr<float>(),
-                          idx.data_ptr<int>(), cur_stream());
+                          idx.data_ptr<int>(), nullptr, 1, cur_stream());
   return {val, idx};
 }
+
+void gemm_force_config(int64_t cfg) { evgpt::gemm_force_config((int)cfg); }
+void gemm_force_splitk(int64_t sk) { evgpt::gemm_force_splitk((int)sk); }
 
 // ------------------------------------------------------------ event front end
 // x,y,p int32 [n]; returns uint8 [T,H,W,3].  mode 0: last event wins, 1: negative wins.
@@ -516,6 +522,8 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("event_raster(Tensor x, Tensor y, Tensor p, int n_slices, int H, int W, int mode) -> Tensor", &event_raster);
   m.def("event_voxel(Tensor x, Tensor y, Tensor p, Tensor t, int t0, int span, int bins, int H, int W, bool signed_mode, bool by_count) -> (Tensor, Tensor)", &event_voxel);
   m.def("clip_preprocess(Tensor img, Tensor hstart, Tensor hcount, Tensor hweight, Tensor vstart, Tensor vcount, Tensor vweight, int S, int resize_h, int resize_w, int top, int left, float[] mean, float[] stdv) -> Tensor", &clip_preprocess);
+  m.def("gemm_force_config(int cfg) -> ()", &gemm_force_config);
+  m.def("gemm_force_splitk(int sk) -> ()", &gemm_force_splitk);
   m.def("patchify(Tensor px, int P) -> Tensor", &patchify);
   m.def("vit_embed_ln(Tensor tok, Tensor cls, Tensor pos, Tensor w, Tensor b, float eps) -> Tensor", &vit_embed_ln);
   m.def("verify_accept(Tensor pval, Tensor pidx, Tensor draft, int G, Tensor(a!) out_tokens, Tensor(b!) step, Tensor(c!) pos, Tensor(d!) done, Tensor(e!) cur_token, Tensor(f!) result, int eos, Tensor embed, Tensor(g!) x) -> ()", &verify_accept);

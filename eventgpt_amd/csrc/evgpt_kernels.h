@@ -25,9 +25,13 @@ void launch_gemv_logits(const bf16_t* W, const bf16_t* x, const bf16_t* norm_w, 
 
 // ---- gemm.hip
 int gemm_argmax_partials(int M, int N);
+void gemm_force_config(int cfg);  // -1 = automatic; for tuning runs
 void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,
                       const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
-                      float* amax_val, int* amax_idx, hipStream_t st);
+                      float* amax_val, int* amax_idx, float* splitk_ws, int splitk,
+                      hipStream_t st);
+int gemm_splitk(int M, int N, int K);   // planned split count (1 = none); ws = splitk*M*N floats
+void gemm_force_splitk(int sk);         // 0 = automatic; for tuning runs
 
 // ---- event_ops.hip
 void launch_event_raster(const int* x, const int* y, const int* p, int n_events, int n_slices,

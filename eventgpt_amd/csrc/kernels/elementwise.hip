@@ -231,48 +231,70 @@ void launch_swiglu(const bf16_t* in, bf16_t* out, long long M, int I, hipStream_
 
 // ------------------------------------------------- spatio-temporal pooling
 // feats [T][S][C] -> out [(Tn + S)][C]: rows 0..Tn-1 are per-frame means over S
-// (zero rows if Tn > T), rows Tn.. are per-token means over T.  One thread owns
-// one 8-channel chunk of one output row, so both reductions come out of a
-// single launch without atomics.
+// (zero rows if Tn > T), rows Tn.. are per-token means over T.  Both reductions
+// come out of one launch without atomics: the first `sp_blocks` blocks give one
+// thread per (token, 8-channel chunk) summing over the T frames; the remaining
+// blocks each own (frame, 32 chunks) and split the S-long sum over 8 row lanes
+// that combine through LDS.
 __global__ __launch_bounds__(256) void st_pool_kernel(const bf16_t* __restrict__ f,
                                                       bf16_t* __restrict__ out, int T, int S,
-                                                      int C, int Tn) {
+                                                      int C, int Tn, int sp_blocks) {
   const int cpr = C >> 3;
-  const int rows = Tn + S;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * cpr; i += gridDim.x * 256) {
-    const int r = i / cpr, c = i % cpr;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float inv;
-    if (r < Tn) {
-      inv = 1.f / static_cast<float>(S);
-      if (r < T) {
-        for (int s = 0; s < S; ++s) {
-          u32x4_t v = load16(f + (static_cast<size_t>(r) * S + s) * C + c * 8);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { acc[2 * j] += bf16lo(v[j]); acc[2 * j + 1] += bf16hi(v[j]); }
-        }
-      }
-    } else {
-      inv = 1.f / static_cast<float>(T);
-      const int s = r - Tn;
+  if (static_cast<int>(blockIdx.x) < sp_blocks) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < S * cpr; i += sp_blocks * 256) {
+      const int s = i / cpr, c = i % cpr;
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int t = 0; t < T; ++t) {
         u32x4_t v = load16(f + (static_cast<size_t>(t) * S + s) * C + c * 8);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { acc[2 * j] += bf16lo(v[j]); acc[2 * j + 1] += bf16hi(v[j]); }
       }
+      const float inv = 1.f / static_cast<float>(T);
+      u32x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(acc[2 * j] * inv, acc[2 * j + 1] * inv);
+      *reinterpret_cast<u32x4_t*>(out + static_cast<size_t>(Tn + s) * C + c * 8) = o;
+    }
+    return;
+  }
+  __shared__ float part[8][32][8];
+  const int groups = (cpr + 31) / 32;
+  const int tb = blockIdx.x - sp_blocks;
+  const int t = tb / groups, cg = tb % groups;
+  const int sl = threadIdx.x >> 5, c = cg * 32 + (threadIdx.x & 31);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (t < T && c < cpr) {
+    for (int s = sl; s < S; s += 8) {
+      u32x4_t v = load16(f + (static_cast<size_t>(t) * S + s) * C + c * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[2 * j] += bf16lo(v[j]); acc[2 * j + 1] += bf16hi(v[j]); }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[sl][threadIdx.x & 31][j] = acc[j];
+  __syncthreads();
+  if (sl == 0 && c < cpr) {
+    const float inv = 1.f / static_cast<float>(S);
+    float tot[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      tot[j] = 0.f;
+      for (int k = 0; k < 8; ++k) tot[j] += part[k][threadIdx.x & 31][j];
     }
     u32x4_t o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(acc[2 * j] * inv, acc[2 * j + 1] * inv);
-    *reinterpret_cast<u32x4_t*>(out + static_cast<size_t>(r) * C + c * 8) = o;
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(tot[2 * j] * inv, tot[2 * j + 1] * inv);
+    *reinterpret_cast<u32x4_t*>(out + static_cast<size_t>(t) * C + c * 8) = o;
   }
 }
 
 void launch_st_pool(const bf16_t* f, bf16_t* out, int T, int S, int C, int Tn, hipStream_t st) {
-  const int work = (Tn + S) * (C / 8);
-  int blocks = (work + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(st_pool_kernel, dim3(blocks), dim3(256), 0, st, f, out, T, S, C, Tn);
+  const int cpr = C / 8;
+  int sp_blocks = (S * cpr + 255) / 256;
+  if (sp_blocks > 2048) sp_blocks = 2048;
+  const int t_blocks = Tn * ((cpr + 31) / 32);
+  hipLaunchKernelGGL(st_pool_kernel, dim3(sp_blocks + t_blocks), dim3(256), 0, st, f, out, T, S, C,
+                     Tn, sp_blocks);
 }
 
 // ----------------------------------------------------------------- argmax

@@ -46,9 +46,34 @@ struct GemmParams {
   // materialised bf16 C without ever writing it.
   float* amax_val;
   int* amax_idx;
+  // split-K: blockIdx = tile * splitk + ks; each split covers k_per_split (a
+  // multiple of 64) of K and stores its raw fp32 tile to partial[ks][M][N]; a
+  // second launch sums the slabs and applies the epilogue.
+  int splitk, k_per_split;
+  float* partial;
 };
 
-template <int BM, int BN, int WGM, int WGN>
+// wait until at most `n` of this wave's direct-to-LDS loads are still in flight
+template <int N> __device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N <= 24, "vmcnt literal");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else static_assert(N == 0, "add the literal");
+}
+
+template <int BM, int BN, int WGM, int WGN, int STAGES>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   constexpr int WM = BM / WGM, WN = BN / WGN;  // per-wave tile
   constexpr int TM = WM / 16, TN = WN / 16;    // 16x16 tiles per wave
@@ -59,7 +84,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n * p.splitk);
+  const int tile = bid / p.splitk, ksplit = bid % p.splitk;
+  const int k_begin = ksplit * p.k_per_split;
+  const int k_len = min(p.k_per_split, p.K - k_begin);
   // consecutive tiles walk down M first: they share one weight panel
   const int tm = tile % tiles_m, tn = tile / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -69,7 +97,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   const int srow = lane >> 3, schunk = lane & 7;
   auto stage = [&](int buf, int kt) {
     unsigned char* base = smem + buf * STAGE;
-    const int k0 = kt * BK;
+    const int k0 = k_begin + kt * BK;
 #pragma unroll
     for (int i = 0; i < BM / 32; ++i) {  // BM/8 row-groups over 4 waves
       const int rg = wid * (BM / 32) + i;
@@ -98,15 +126,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 
   const int frow = lane & 15, fq = lane >> 4;
   const int fsw = (frow >> 1) & 7;  // swizzle term: tile bases are multiples of 16 rows
-  const int nk = p.K / BK;
+  const int nk = k_len / BK;
 
-  stage(0, 0);
-  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) & lgkmcnt(0)
-  __syncthreads();
+  // STAGES-deep ring, STAGES-1 K-tiles in flight.  Direct-to-LDS loads are
+  // tracked by vmcnt, so "tile kt has landed" is a *counted* wait that leaves the
+  // younger tiles' loads outstanding, followed by a raw s_barrier (a
+  // __syncthreads() would drain them all).  After the barrier every wave has
+  // finished reading the buffer of tile kt-1, which is the one re-staged next.
+  constexpr int G = (BM + BN) / 32;  // direct-to-LDS instructions per wave per stage
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) stage(s, s);
 
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const int ahead = min(STAGES - 2, nk - 1 - kt);
+    if (ahead <= 0) wait_vm<0>();
+    else if (ahead == 1) wait_vm<G>();
+    else if (ahead == 2) wait_vm<2 * G>();
+    else wait_vm<3 * G>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + STAGES - 1 < nk) {
+      int nb = cur + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      stage(nb, kt + STAGES - 1);
+    }
     const unsigned char* a_base = smem + cur * STAGE + (wr * WM + frow) * 128;
     const unsigned char* b_base = smem + cur * STAGE + A_BYTES + (wc * WN + frow) * 128;
 #pragma unroll
@@ -125,11 +169,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();  // drains the direct-to-LDS loads of tile kt+1 and orders buffer reuse
-    cur ^= 1;
+    cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
 
   // ---- epilogue: lane holds C[m][n .. n+3]
+  if (p.splitk > 1) {
+    float* slab = p.partial + static_cast<size_t>(ksplit) * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wr * WM + i * 16 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wc * WN + j * 16 + fq * 4;
+        float* dst = slab + static_cast<size_t>(m) * p.N + n;
+        if (n + 3 < p.N && (p.N & 3) == 0) {
+          *reinterpret_cast<f32x4_t*>(dst) = acc[i][j];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wr * WM + i * 16 + frow;
@@ -198,29 +261,132 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+// out = act(sum_s partial[s] + bias) + res, 4 columns per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
+  const long long quads = (static_cast<long long>(p.M) * p.N + 3) / 4;
+  const size_t slab = static_cast<size_t>(p.M) * p.N;
+  for (long long q = blockIdx.x * 256ll + threadIdx.x; q < quads; q += gridDim.x * 256ll) {
+    const size_t e0 = static_cast<size_t>(q) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = (p.N & 3) == 0;
+    for (int s = 0; s < p.splitk; ++s) {
+      if (vec) {
+        const f32x4_t t = *reinterpret_cast<const f32x4_t*>(p.partial + s * slab + e0);
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+      } else {
+        for (int r = 0; r < 4; ++r) if (e0 + r < slab) v[r] += p.partial[s * slab + e0 + r];
+      }
+    }
+    for (int r = 0; r < 4; ++r) {
+      const size_t e = e0 + r;
+      if (e >= slab) break;
+      const int m = static_cast<int>(e / p.N), n = static_cast<int>(e % p.N);
+      float x = v[r];
+      if (p.bias) x += bf16_to_f32(p.bias[n]);
+      x = apply_act(x, p.act);
+      const size_t o = static_cast<size_t>(m) * p.ldc + n;
+      if (p.res) x = bf16_to_f32(f32_to_bf16(x)) + bf16_to_f32(p.res[o]);
+      if (p.Cf) p.Cf[o] = x;
+      if (p.C) p.C[o] = f32_to_bf16(x);
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int STAGES>
 static void launch_cfg(const GemmParams& p, hipStream_t st) {
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  const size_t smem = 2 * (BM + BN) * BK * 2;
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN>), dim3(tiles), dim3(256), smem, st, p);
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk;
+  constexpr size_t smem = static_cast<size_t>(STAGES) * (BM + BN) * BK * 2;
+  static bool attr_set = false;
+  if (smem > 64 * 1024 && !attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES>), dim3(tiles), dim3(256), smem,
+                     st, p);
+}
+
+// Tile choice: the largest tile that still puts >= ~1.5 blocks on each of the 256
+// CUs; shapes that cannot (prefill of a few hundred rows against a 1024- or
+// 4096-wide matrix, verify batches) take smaller tiles with a deeper ring, since
+// a grid below one block per CU is bound by the latency of its own K loop.
+enum GemmCfg { CFG_128x128 = 0, CFG_64x128 = 1, CFG_64x64 = 2, CFG_32x64 = 3, CFG_32x128 = 4 };
+
+static int g_forced_cfg = -1;
+void gemm_force_config(int cfg) { g_forced_cfg = cfg; }
+
+static GemmCfg pick_cfg(int M, int N) {
+  if (g_forced_cfg >= 0) return static_cast<GemmCfg>(g_forced_cfg);
+  auto tiles = [&](int bm, int bn) {
+    return static_cast<long long>((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  };
+  // thresholds from benchmarks/bench_gemm.py on MI355X
+  if (M <= 32) return tiles(32, 128) >= 256 ? CFG_32x128 : CFG_32x64;
+  if (tiles(128, 128) >= 384) return CFG_128x128;
+  if (tiles(64, 128) >= 300) return CFG_64x128;
+  if (tiles(64, 64) >= 300) return CFG_64x64;
+  return CFG_32x64;
+}
+
+static long long cfg_tiles(GemmCfg c, int M, int N) {
+  static const int bm[] = {128, 64, 64, 32, 32}, bn[] = {128, 128, 64, 64, 128};
+  return static_cast<long long>((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]);
+}
+
+static int g_forced_splitk = 0;
+void gemm_force_splitk(int sk) { g_forced_splitk = sk; }
+
+// Split K when the output grid alone cannot fill the chip and K is long enough
+// that every split still runs >= 8 K-steps.
+int gemm_splitk(int M, int N, int K) {
+  if (g_forced_splitk > 0) return (K / 64) >= g_forced_splitk ? g_forced_splitk : 1;
+  // measured (benchmarks/bench_gemm.py): the extra reduce pass only pays for
+  // weight-streaming shapes with a handful of rows (batched decode, verify)
+  if (M > 32) return 1;
+  const long long t = cfg_tiles(pick_cfg(M, N), M, N);
+  if (t >= 256) return 1;
+  int sk = static_cast<int>((256 + t - 1) / t);
+  const int max_by_k = (K / 64) / 8;
+  if (sk > max_by_k) sk = max_by_k;
+  if (sk > 16) sk = 16;
+  return sk < 2 ? 1 : sk;
 }
 
 int gemm_argmax_partials(int M, int N) {
-  // must mirror the tile choice in launch_gemm_bf16
-  if (M <= 32) return ((N + 127) / 128) * 4;
-  return ((N + 127) / 128) * 2;
+  switch (pick_cfg(M, N)) {  // tiles_n * WGN of the chosen config
+    case CFG_128x128: case CFG_64x128: return ((N + 127) / 128) * 2;
+    case CFG_64x64: return ((N + 63) / 64) * 2;
+    case CFG_32x64: return ((N + 63) / 64) * 4;
+    default: return ((N + 127) / 128) * 4;
+  }
 }
 
 void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,
                       const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
-                      float* amax_val, int* amax_idx, hipStream_t st) {
-  GemmParams p{A, W, C, bias, res, Cf, M, N, K, lda, ldw, ldc, act, amax_val, amax_idx};
-  // Tile choice: fill 256 CUs.  Small M (prefill of a few hundred rows, verify
-  // batches) uses shorter tiles so the grid is not a fraction of the chip.
-  const long long t128 = static_cast<long long>((M + 127) / 128) * ((N + 127) / 128);
-  if (M <= 32) launch_cfg<32, 128, 1, 4>(p, st);
-  else if (M <= 64 || t128 < 256) launch_cfg<64, 128, 2, 2>(p, st);
-  else launch_cfg<128, 128, 2, 2>(p, st);
+                      float* amax_val, int* amax_idx, float* splitk_ws, int splitk,
+                      hipStream_t st) {
+  GemmParams p{A, W, C, bias, res, Cf, M, N, K, lda, ldw, ldc, act, amax_val, amax_idx, 1, K,
+               nullptr};
+  if (splitk > 1 && splitk_ws && !amax_val) {
+    const int ksteps = K / 64;
+    p.splitk = splitk;
+    p.k_per_split = ((ksteps + splitk - 1) / splitk) * 64;
+    p.splitk = (K + p.k_per_split - 1) / p.k_per_split;  // drop empty trailing splits
+    p.partial = splitk_ws;
+  }
+  switch (pick_cfg(M, N)) {
+    case CFG_128x128: launch_cfg<128, 128, 2, 2, 2>(p, st); break;
+    case CFG_64x128: launch_cfg<64, 128, 2, 2, 3>(p, st); break;
+    case CFG_64x64: launch_cfg<64, 64, 2, 2, 4>(p, st); break;
+    case CFG_32x64: launch_cfg<32, 64, 1, 4, 4>(p, st); break;
+    default: launch_cfg<32, 128, 1, 4, 4>(p, st); break;
+  }
+  if (p.splitk > 1) {
+    const long long quads = (static_cast<long long>(M) * N + 3) / 4;
+    int blocks = static_cast<int>((quads + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+  }
 }
 
 }  // namespace evgpt
