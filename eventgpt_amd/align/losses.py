@@ -1,0 +1,87 @@
+"""Losses for hidden-state alignment.
+
+One implementation shared by every adapter level (the reference repeats it per
+class, e.g. pipeline/adapter_train/hidden_adapter.py:164-215, 831-898):
+
+    align  = masked MSE(pred, target) + 0.5 * (1 - masked mean cosine)
+    pred   = masked MSE(pred[:, :-1], target[:, 1:])            (next-position)
+    total  = (1 - w) * align + w * pred                          (w = 0 for L1-L4)
+
+Masks are ``[B, S]`` with 1 for valid positions.  The MSE is averaged over valid
+*elements* (positions x hidden), the cosine over valid positions.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+def masked_mse(pred: torch.Tensor, target: torch.Tensor,
+               mask: Optional[torch.Tensor]) -> torch.Tensor:
+    se = (pred - target).pow(2)
+    if mask is None:
+        return se.mean()
+    m = mask.to(se.dtype).unsqueeze(-1)
+    return (se * m).sum() / (m.sum() * se.shape[-1]).clamp_min(1.0)
+
+
+def cosine_per_position(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """``[B, S]`` cosine similarity between matching rows."""
+    return (F.normalize(pred, dim=-1) * F.normalize(target, dim=-1)).sum(dim=-1)
+
+
+def masked_mean(values: torch.Tensor, mask: Optional[torch.Tensor]) -> torch.Tensor:
+    if mask is None:
+        return values.mean()
+    m = mask.to(values.dtype)
+    return (values * m).sum() / m.sum().clamp_min(1.0)
+
+
+def alignment_losses(pred: torch.Tensor, target: torch.Tensor,
+                     mask: Optional[torch.Tensor] = None,
+                     prediction_weight: float = 0.0) -> Dict[str, torch.Tensor]:
+    mse = masked_mse(pred, target, mask)
+    cos_sim = masked_mean(cosine_per_position(pred, target), mask)
+    cos_loss = 1.0 - cos_sim
+    align = mse + 0.5 * cos_loss
+    out = {"mse_loss": mse, "cos_loss": cos_loss, "cos_sim": cos_sim}
+    if prediction_weight > 0.0:
+        if pred.shape[1] > 1:
+            pred_loss = masked_mse(pred[:, :-1], target[:, 1:],
+                                   None if mask is None else mask[:, 1:])
+        else:
+            pred_loss = pred.new_zeros(())
+        out["pred_loss"] = pred_loss
+        out["align_loss"] = align
+        out["total_loss"] = (1.0 - prediction_weight) * align + prediction_weight * pred_loss
+    else:
+        out["total_loss"] = align
+    return out
+
+
+def acceptance_rates(cos: torch.Tensor, thresholds=(0.80, 0.85, 0.90, 0.95)) -> Dict[str, float]:
+    """Fraction of positions whose cosine exceeds each threshold (keys ``accept_80`` ...)."""
+    cos = cos.float()
+    if cos.numel() == 0:
+        return {f"accept_{int(round(t * 100))}": 0.0 for t in thresholds}
+    return {f"accept_{int(round(t * 100))}": float((cos > t).float().mean()) for t in thresholds}
+
+
+def lora_distill_loss(pred_hidden: torch.Tensor, target_hidden: torch.Tensor,
+                      lm_head_weight: torch.Tensor, cos_weight: float = 0.5,
+                      ce_weight: float = 0.1) -> Dict[str, torch.Tensor]:
+    """``MSE + 0.5*CosineEmbedding + 0.1*CE(lm_head(pred), argmax lm_head(target))``
+    (reference: pipeline/adapter_train/train_lora_adapter.py:692-707)."""
+    p = pred_hidden.float().reshape(-1, pred_hidden.shape[-1])
+    t = target_hidden.float().reshape(-1, target_hidden.shape[-1])
+    mse = F.mse_loss(p, t)
+    cos = F.cosine_embedding_loss(p, t, torch.ones(p.shape[0], device=p.device))
+    w = lm_head_weight.float()
+    with torch.no_grad():
+        tgt_tok = (t @ w.t()).argmax(-1)
+    ce = F.cross_entropy(p @ w.t(), tgt_tok)
+    return {"total_loss": mse + cos_weight * cos + ce_weight * ce, "mse_loss": mse,
+            "cos_loss": cos, "ce_loss": ce,
+            "cos_sim": cosine_per_position(p, t).mean()}
