@@ -41,9 +41,8 @@ struct GemmParams {
   const bf16_t* res;   // [M][ldc] or null (may alias C)
   float* Cf;           // optional fp32 output [M][ldc] (C may be null)
   int M, N, K, lda, ldw, ldc, act;
-  // optional row-argmax partials: [M][n_part] (value, index), n_part = tiles_n * WGN.
-  // Values are the bf16-rounded outputs, so the result equals argmax over a
-  // materialised bf16 C without ever writing it.
+  // optional row-argmax partials: [M][n_part] (value, index), n_part = tiles_n * WGN,
+  // taken on the fp32 accumulators so C is never written.
   float* amax_val;
   int* amax_idx;
   // split-K: blockIdx = tile * splitk + ks; each split covers k_per_split (a
@@ -208,7 +207,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
           const int n = n0 + wc * WN + j * 16 + fq * 4 + r;
           float v = acc[i][j][r];
           if (p.bias && n < p.N) v += bf16_to_f32(p.bias[n]);
-          v = bf16_to_f32(f32_to_bf16(v));
           if (n < p.N && (v > bv || (v == bv && n < bi))) { bv = v; bi = n; }
         }
 #pragma unroll

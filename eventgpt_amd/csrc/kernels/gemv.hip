@@ -207,8 +207,9 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           if (row[r] < p.N) {
-            // logits are rounded to bf16 like the reference's lm_head output
-            const float v = bf16_to_f32(f32_to_bf16(acc[r][b]));
+            // fp32 logits: rounding them to bf16 would turn near-ties into exact
+            // ties, and a greedy decode must agree with a batched verify of it
+            const float v = acc[r][b];
             if (lane == 0 && p.logits) p.logits[static_cast<size_t>(b) * p.N + row[r]] = v;
             if (v > best_val[b]) { best_val[b] = v; best_idx[b] = row[r]; }
           }

@@ -1,0 +1,108 @@
+"""GPU event front end: events -> raster frames -> CLIP-normalised bf16 pixels.
+
+Replaces the reference's host pipeline (python loop over every event to paint
+the raster, PIL resize, numpy normalise — common/common.py:17-37,64-74,110-129)
+with three launches on device-resident event arrays:
+
+    event_raster    one atomic per event (last-wins / negative-wins), all T slices
+    clip_preprocess PIL-exact two-pass bicubic + crop + normalise, all T frames
+    (event_voxel    time-binned polarity histogram / signed voxel grid)
+
+The resample tables are the ones ``data.clip_preprocess`` builds, so device and
+host produce bit-identical uint8 images.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..constants import CLIP_IMAGE_SIZE, CLIP_MEAN, CLIP_STD
+from ..data import clip_preprocess as cp
+from ..data.events import canvas_size
+
+_TABLE_CACHE: Dict[tuple, tuple] = {}
+
+
+def events_to_device(events: dict, device) -> Dict[str, torch.Tensor]:
+    """int32 x/y/p and int64 t tensors on ``device`` (one H2D copy each)."""
+    out = {}
+    for k in ("x", "y", "p"):
+        out[k] = torch.from_numpy(np.ascontiguousarray(events[k]).astype(np.int32)).to(device)
+    out["t"] = torch.from_numpy(np.ascontiguousarray(events["t"]).astype(np.int64)).to(device)
+    return out
+
+
+def rasterize_gpu(ev: Dict[str, torch.Tensor], n_slices: int = 5,
+                  size: Optional[Tuple[int, int]] = None, conflict: str = "last") -> torch.Tensor:
+    """``uint8 [T, H, W, 3]``.  Every slice is painted on a canvas of the given (or
+    whole-stream) extent.  NOTE: the host path sizes each slice's canvas from that
+    slice's own max coordinates; pass ``size`` to pin it."""
+    from . import hip
+    if size is None:
+        size = (int(ev["y"].max()) + 1, int(ev["x"].max()) + 1)
+    mode = {"last": 0, "negative": 1}[conflict]
+    return hip.raw.event_raster(ev["x"], ev["y"], ev["p"], n_slices, size[0], size[1], mode)
+
+
+def voxel_grid_gpu(ev: Dict[str, torch.Tensor], bins: int = 5,
+                   size: Optional[Tuple[int, int]] = None, signed: bool = True,
+                   by: str = "time") -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(hist int32 [bins,2,H,W], voxel fp32 [bins,H,W])``."""
+    from . import hip
+    if size is None:
+        size = (int(ev["y"].max()) + 1, int(ev["x"].max()) + 1)
+    t0 = int(ev["t"].min()) if ev["t"].numel() else 0
+    span = max(int(ev["t"].max()) - t0, 1) if ev["t"].numel() else 1
+    return hip.raw.event_voxel(ev["x"], ev["y"], ev["p"], ev["t"], t0, span, bins, size[0],
+                               size[1], signed, by == "count")
+
+
+def _tables(h: int, w: int, size: int, device) -> tuple:
+    key = (h, w, size, str(device))
+    hit = _TABLE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    rh, rw = cp.resized_shape(h, w, size)
+    top, left = cp.center_crop_offsets(rh, rw, size)
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+
+    dummy = dev(np.zeros(1))
+    if rw != w:
+        th = cp.resample_table(w, rw)
+        hs, hc, hw = dev(th.start), dev(th.count), dev(th.weight)
+    else:
+        hs = hc = dummy
+        hw = dev(np.zeros((1, 1)))
+    if rh != h:
+        tv = cp.resample_table(h, rh)
+        vs, vc, vw = dev(tv.start), dev(tv.count), dev(tv.weight)
+    else:
+        vs = vc = dummy
+        vw = dev(np.zeros((1, 1)))
+    out = (hs, hc, hw, vs, vc, vw, rh, rw, top, left)
+    _TABLE_CACHE[key] = out
+    return out
+
+
+def clip_preprocess_gpu(frames_u8: torch.Tensor, size: int = CLIP_IMAGE_SIZE) -> torch.Tensor:
+    """``uint8 [T,H,W,3]`` on the GPU -> ``bf16 [T,3,size,size]``."""
+    from . import hip
+    t, h, w, _ = frames_u8.shape
+    hs, hc, hw, vs, vc, vw, rh, rw, top, left = _tables(h, w, size, frames_u8.device)
+    if rh < size or rw < size:
+        raise ValueError("image too small to crop after resize")
+    return hip.raw.clip_preprocess(frames_u8.contiguous(), hs, hc, hw, vs, vc, vw, size, rh, rw,
+                                   top, left, list(CLIP_MEAN), list(CLIP_STD))
+
+
+def event_frames_gpu(events: dict, device, n_frames: int = 5, size: int = CLIP_IMAGE_SIZE,
+                     conflict: str = "last") -> Tuple[list, torch.Tensor]:
+    """Host event dict -> ``([H, W], bf16 [T,3,size,size])`` entirely on the GPU."""
+    ev = events_to_device(events, device)
+    hw = canvas_size(np.asarray(events["x"]), np.asarray(events["y"]))
+    img = rasterize_gpu(ev, n_frames, hw, conflict)
+    return list(hw), clip_preprocess_gpu(img, size)

@@ -128,6 +128,7 @@ class GenerationEngine:
         self.done = torch.zeros(B, **i32)
         self.cur_token = torch.zeros(B, **i32)
         self.sampled = torch.zeros(B, **i32)
+        self.sd_result = torch.zeros(4, **i32)  # [n_accepted, next_token, n_emitted, -]
         self.eos = int(cfg.eos_token_id if cfg.eos_token_id is not None else -1)
         self._graph_greedy = None
         self._graph_logits = None
@@ -160,15 +161,31 @@ class GenerationEngine:
         ``None`` only fills the cache.  Returns the last-layer hidden states
         ``[S, H]`` (before the final norm) if ``return_hidden``.
         """
-        raw = self.raw
         S = embeds.shape[0]
         if start is None:
             start = int(self.pos[batch].item())
         if start + S > self.l_max:
             raise ValueError(f"sequence of {start + S} tokens exceeds the cache ({self.l_max})")
-        x = embeds.to(torch.bfloat16).contiguous().view(1, S, self.H)
         pos0 = torch.tensor([start], dtype=torch.int32, device=self.device)
-        kv_len = torch.tensor([start + S], dtype=torch.int32, device=self.device)
+        x = self._forward_rows(embeds, batch, pos0)
+        if select is None:
+            self.pos[batch] = start + S
+        else:
+            # the commit kernel advances pos by one, like a decode step does
+            self.pos[batch] = start + S - 1
+            self.x[batch].copy_(x[0, -1])
+            self._logits_and_commit(greedy=(select == "greedy"))
+        return x[0] if return_hidden else None
+
+    def _forward_rows(self, embeds: torch.Tensor, batch: int, pos0: torch.Tensor) -> torch.Tensor:
+        """All decoder layers over ``embeds [S, H]`` placed at cache positions
+        ``pos0[0] .. pos0[0]+S-1`` of sequence ``batch`` (``pos0`` is a device int32
+        tensor, so no host sync).  Returns hidden states ``[1, S, H]`` before the
+        final norm.  Does not touch the position counters."""
+        raw = self.raw
+        S = embeds.shape[0]
+        x = embeds.to(torch.bfloat16).contiguous().view(1, S, self.H)
+        kv_len = pos0 + S
         q = torch.empty(1, S, self.Hq, self.D, dtype=torch.bfloat16, device=self.device)
         o = torch.empty_like(q)
         for l in self.layers:
@@ -181,14 +198,35 @@ class GenerationEngine:
             xn = raw.rmsnorm(x, l.norm2, self.eps)
             gu = raw.linear(xn, l.w_gate_up, None, None, 0, False)
             x = raw.linear(raw.swiglu(gu), l.w_down, None, x, 0, False)
-        if select is None:
-            self.pos[batch] = start + S
-        else:
-            # the commit kernel advances pos by one, like a decode step does
-            self.pos[batch] = start + S - 1
-            self.x[batch].copy_(x[0, -1])
-            self._logits_and_commit(greedy=(select == "greedy"))
-        return x[0] if return_hidden else None
+        return x
+
+    # ----------------------------------------------------- speculative verify
+    @torch.no_grad()
+    def verify(self, draft: torch.Tensor, n_draft: Optional[int] = None,
+               return_hidden: bool = False):
+        """Verify ``draft`` (device int32 ``[G]``) against this model in ONE forward.
+
+        The G+1 tokens ``[current, d1..dG]`` are embedded on the device, run through
+        the layers at cache positions ``pos..pos+G``, and the lm_head GEMM leaves
+        only per-row argmax partials; the fused accept kernel then finds the agreed
+        prefix, appends accepted + correction/bonus tokens to the output ring,
+        advances ``pos`` (KV rollback = the counter; rejected slots are simply
+        overwritten later), flags EOS and stages the next embedding.  Nothing is
+        read back: ``self.sd_result`` holds ``[n_accepted, next_token, n_emitted]`` on
+        the device.  Returns the G+1 hidden rows (post final-norm) if asked — the
+        verifier-side states that B1 / L5F adapters consume.
+        """
+        raw = self.raw
+        G = int(draft.shape[0]) if n_draft is None else int(n_draft)
+        toks = torch.cat([self.cur_token[:1], draft[:G].to(torch.int32)]).long()
+        emb = self.embed.index_select(0, toks.clamp_(0, self.embed.shape[0] - 1))
+        h = self._forward_rows(emb, 0, self.pos[:1])
+        hn = raw.rmsnorm(h, self.final_norm, self.eps)
+        pv, pi = raw.linear_argmax_partials(hn.view(G + 1, self.H), self.lm_head, None)
+        raw.verify_accept(pv, pi, draft.to(torch.int32).contiguous(), G, self.out_tokens, self.step,
+                          self.pos, self.done, self.cur_token, self.sd_result, self.eos,
+                          self.embed, self.x)
+        return hn.view(G + 1, self.H) if return_hidden else None
 
     # ------------------------------------------------------------ decode step
     def _layers_step(self) -> None:
@@ -285,17 +323,27 @@ class GenerationEngine:
         self.prefill(embeds, select="greedy" if greedy else "logits")
         if not greedy:
             self._sample_and_commit(temperature, top_p, generator)
-        n = 1
         budget = min(max_new_tokens, self.l_max - embeds.shape[0])
-        while n < budget:
+        return self.generate_continue(budget, None, temperature, top_p, generator)
+
+    @torch.no_grad()
+    def generate_continue(self, max_new_tokens: int, eos_token_id: Optional[int] = None,
+                          temperature: float = 0.0, top_p: float = 1.0,
+                          generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """Keep decoding sequence 0 until ``max_new_tokens`` tokens have been emitted in
+        total (counting those already committed) or EOS; returns all emitted tokens."""
+        if eos_token_id is not None:
+            self.eos = int(eos_token_id)
+        greedy = temperature <= 0
+        n = int(self.step[0].item())
+        budget = min(max_new_tokens, self.max_out)
+        while n < budget and not int(self.done[0].item()):
             chunk = min(self.poll_every, budget - n)
             for _ in range(chunk):
                 self.decode_step(greedy)
                 if not greedy:
                     self._sample_and_commit(temperature, top_p, generator)
             n += chunk
-            if int(self.done[0].item()):
-                break
         toks = self.out_tokens[0, :n].to(torch.long)
         if self.eos >= 0:
             hit = (toks == self.eos).nonzero()

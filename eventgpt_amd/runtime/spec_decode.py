@@ -1,0 +1,258 @@
+"""Speculative decoding runtime: a fast drafter proposes, a slow verifier checks.
+
+Pieces (reference counterparts in brackets):
+
+* ``NaiveSpeculativeDecoder`` — token-level greedy SD between two models that
+  share a vocabulary, with KV caches on both sides
+  [feasible/naive_speculative_decoding.py:7-60, which re-runs the whole sequence
+  every step].
+* ``AdapterDraftHead`` — drafter hidden states -> hidden adapter -> verifier
+  ``lm_head`` -> argmax, with the GEMM's epilogue producing the argmax so logits
+  are never materialised [benchmark_e2e_wallclock.py:996-1001].
+* ``SpecDecodeEngine`` — the cross-modal loop: adapter-drafted SD with a fixed
+  gamma, the gamma=1 feedback modes (B1 / L5F consume verifier hidden states),
+  and prefill hiding (verify every token the drafter produced while the
+  verifier was still prefilling, in one batch) [run_sd_decode :860-1032,
+  vl_verify_batch :569-637, sequential_egpt_vl_prefill :722-853].
+
+Every verify step is ``GenerationEngine.verify``: one forward over gamma+1 rows
+and a fused accept kernel; acceptance, the bonus token, EOS and KV rollback
+happen on the device.  The host reads back three integers per round for
+statistics and loop control.  Output is lossless: the emitted sequence equals
+the verifier's own greedy decode.
+"""
+from __future__ import annotations
+
+import dataclasses
+import time
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from .. import ops
+
+
+@dataclasses.dataclass
+class SDStats:
+    total_drafted: int = 0
+    total_accepted: int = 0
+    iterations: int = 0
+    fallback_steps: int = 0
+    tokens: int = 0
+    decode_ms: float = 0.0
+
+    @property
+    def accept_rate(self) -> float:
+        return self.total_accepted / self.total_drafted if self.total_drafted else 0.0
+
+    @property
+    def tokens_per_iter(self) -> float:
+        return self.tokens / self.iterations if self.iterations else 0.0
+
+    def as_dict(self) -> Dict[str, float]:
+        return {"total_drafted": self.total_drafted, "total_accepted": self.total_accepted,
+                "iterations": self.iterations, "fallback_steps": self.fallback_steps,
+                "accept_rate": self.accept_rate, "tokens_per_iter": self.tokens_per_iter,
+                "tokens": self.tokens, "decode_ms": self.decode_ms}
+
+
+def _emitted(engine) -> torch.Tensor:
+    n = int(engine.step[0].item())
+    return engine.out_tokens[0, :n].to(torch.long)
+
+
+class AdapterDraftHead:
+    """``adapter(hidden) @ lm_head^T -> argmax`` as draft tokens (device int32)."""
+
+    def __init__(self, adapter: torch.nn.Module, lm_head_weight: torch.Tensor):
+        self.adapter = adapter.eval()
+        self.dtype = next(adapter.parameters()).dtype
+        self.w = lm_head_weight
+        self._w_bf16 = None
+
+    @torch.no_grad()
+    def __call__(self, hidden: torch.Tensor, verifier_hidden: Optional[torch.Tensor] = None) -> torch.Tensor:
+        h = hidden.to(self.dtype)
+        if h.ndim == 2:
+            h = h[None]
+        if getattr(self.adapter, "takes_target_input", False):
+            aligned = self.adapter(h, verifier_hidden.to(self.dtype).view(1, -1, h.shape[-1]))
+        else:
+            aligned = self.adapter(h)
+        aligned = aligned[0]
+        if aligned.is_cuda and aligned.shape[-1] % 64 == 0:
+            from ..ops import hip
+            if self._w_bf16 is None:
+                self._w_bf16 = self.w.to(torch.bfloat16).contiguous()
+            pv, pi = hip.raw.linear_argmax_partials(aligned.to(torch.bfloat16).contiguous(),
+                                                    self._w_bf16, None)
+            best = pv.argmax(dim=1, keepdim=True)
+            return pi.gather(1, best)[:, 0].to(torch.int32)
+        return (aligned.float() @ self.w.float().t()).argmax(-1).to(torch.int32)
+
+
+class NaiveSpeculativeDecoder:
+    """Greedy token-level SD.  ``draft`` and ``target`` are ``GenerationEngine``s over
+    the same vocabulary; both keep their KV caches and roll back by position."""
+
+    def __init__(self, draft_engine, target_engine, tokenizer=None):
+        self.draft, self.target, self.tokenizer = draft_engine, target_engine, tokenizer
+
+    @torch.no_grad()
+    def generate(self, draft_embeds: torch.Tensor, target_embeds: Optional[torch.Tensor] = None,
+                 max_new_tokens: int = 50, num_draft_tokens: int = 5, eos_token_id: int = -1):
+        """Returns ``(tokens, acceptance_history)``; ``tokens`` equals the target's own
+        greedy continuation of its prompt."""
+        d, t = self.draft, self.target
+        target_embeds = draft_embeds if target_embeds is None else target_embeds
+        d.eos = t.eos = eos_token_id
+        d.reset(); t.reset()
+        t.prefill(target_embeds, select="greedy")          # first token comes from the target
+        d.prefill(draft_embeds, select=None)
+        offset = draft_embeds.shape[0] - target_embeds.shape[0]
+        history: List[float] = []
+        gamma = num_draft_tokens
+        while int(t.step[0].item()) < max_new_tokens and not int(t.done[0].item()):
+            # drafter continues from the target's current token at its own position
+            base = int(t.pos[0].item()) + offset
+            d.pos.fill_(base)
+            d.step.zero_()
+            d.x[0].copy_(d.embed[t.cur_token[0].long()])
+            for _ in range(gamma):
+                d.decode_step(True)
+            draft = d.out_tokens[0, :gamma].clone()
+            t.verify(draft, gamma)
+            n_acc = int(t.sd_result[0].item())
+            history.append(n_acc / gamma)
+            if n_acc == gamma and not int(t.done[0].item()):
+                # every draft token was accepted: the drafter has not yet ingested the
+                # last one (its cache holds pos < base+gamma)
+                d.pos.fill_(base + gamma)
+                d.x[0].copy_(d.embed[draft[gamma - 1].long()])
+                d._layers_step()
+        return _emitted(t)[:max_new_tokens], history
+
+
+class SpecDecodeEngine:
+    """Adapter-drafted speculative decoding against a ``GenerationEngine`` verifier."""
+
+    def __init__(self, verifier_engine, draft_head: Optional[AdapterDraftHead] = None,
+                 gamma: int = 5):
+        self.v = verifier_engine
+        self.head = draft_head
+        self.gamma = gamma
+
+    # ---------------------------------------------------------------- drafting
+    def _verify(self, draft: torch.Tensor, stats: SDStats, want_hidden: bool):
+        g = int(draft.shape[0])
+        hidden = self.v.verify(draft, g, return_hidden=want_hidden)
+        n_acc = int(self.v.sd_result[0].item())
+        stats.total_drafted += g
+        stats.total_accepted += n_acc
+        stats.iterations += 1
+        return n_acc, hidden
+
+    def _ar_step(self, stats: SDStats) -> None:
+        self.v.decode_step(True)
+        stats.fallback_steps += 1
+        stats.iterations += 1
+
+    @torch.no_grad()
+    def run(self, drafter_hidden: Optional[torch.Tensor], max_new_tokens: int = 50,
+            eos_token_id: int = 2, mode: str = "adapter",
+            verifier_prefill_hidden: Optional[torch.Tensor] = None) -> tuple:
+        """SD decode after the verifier has prefilled and committed its first token.
+
+        ``drafter_hidden [N, H]``: the drafter's per-step last-layer hidden states
+        for its own greedy answer (position i drafts verifier token i+1).
+        ``mode``: ``"adapter"`` (L1-L5, one-shot gamma drafts), ``"vlm_only"`` (B1,
+        gamma=1 from the verifier's own last hidden state) or ``"fused"`` (L5F,
+        gamma=1 from drafter + verifier hidden).  Returns ``(tokens, SDStats)``.
+        """
+        v = self.v
+        v.eos = eos_token_id
+        stats = SDStats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        need_vh = mode in ("vlm_only", "fused")
+        last_vh = verifier_prefill_hidden  # [1, H] verifier hidden that predicts the next token
+        n_h = 0 if drafter_hidden is None else drafter_hidden.shape[0]
+        while True:
+            n_out = int(v.step[0].item())
+            if n_out >= max_new_tokens or int(v.done[0].item()):
+                break
+            start = n_out - 1  # index of the drafter state aligned with the current token
+            if need_vh:
+                if last_vh is None or (mode == "fused" and start >= n_h):
+                    self._ar_step(stats)
+                    last_vh = None
+                    continue
+                if mode == "vlm_only":
+                    draft = self.head(last_vh.view(1, -1))
+                else:
+                    draft = self.head(drafter_hidden[start:start + 1], last_vh.view(1, -1))
+                n_acc, vh = self._verify(draft[:1], stats, True)
+                last_vh = vh[n_acc:n_acc + 1]
+            else:
+                end = min(start + self.gamma, n_h)
+                if end - start <= 0:
+                    self._ar_step(stats)
+                    continue
+                draft = self.head(drafter_hidden[start:end])
+                self._verify(draft, stats, False)
+        torch.cuda.synchronize()
+        stats.decode_ms = (time.perf_counter() - t0) * 1e3
+        toks = _emitted(v)[:max_new_tokens]
+        stats.tokens = int(toks.shape[0])
+        return toks, stats
+
+    @torch.no_grad()
+    def verify_free_tokens(self, draft_tokens: torch.Tensor, max_new_tokens: int = 50,
+                           eos_token_id: int = 2, drop_first: bool = True) -> tuple:
+        """Prefill hiding: the drafter produced ``draft_tokens`` while the verifier was
+        prefilling.  They are checked in ONE batched verify, then the verifier
+        continues autoregressively.  ``drop_first``: the first draft token
+        duplicates the verifier's own first token and is skipped
+        (benchmark_e2e_wallclock.py:1766-1773)."""
+        v = self.v
+        v.eos = eos_token_id
+        stats = SDStats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d = draft_tokens[1:] if drop_first else draft_tokens
+        d = d[: min(d.shape[0], 63, max_new_tokens - 1)]
+        if d.shape[0] > 0:
+            self._verify(d.to(torch.int32), stats, False)
+        while int(v.step[0].item()) < max_new_tokens and not int(v.done[0].item()):
+            remaining = max_new_tokens - int(v.step[0].item())
+            for _ in range(min(v.poll_every, remaining)):
+                v.decode_step(True)
+                stats.fallback_steps += 1
+        torch.cuda.synchronize()
+        stats.decode_ms = (time.perf_counter() - t0) * 1e3
+        toks = _emitted(v)[:max_new_tokens]
+        if eos_token_id >= 0:
+            hit = (toks == eos_token_id).nonzero()
+            if hit.numel():
+                toks = toks[: int(hit[0]) + 1]
+        stats.tokens = int(toks.shape[0])
+        return toks, stats
+
+
+def collect_decode_hidden(engine, embeds: torch.Tensor, max_new_tokens: int,
+                          eos_token_id: int = -1) -> Dict[str, torch.Tensor]:
+    """Greedy decode on ``engine`` keeping, per generated token, the final-norm hidden
+    state that produced it — the drafter-side input of the hidden adapters
+    [egpt_decode_collect_hidden, benchmark_e2e_wallclock.py:417-472].  Runs eagerly
+    (one small copy per step between graph replays)."""
+    engine.eos = eos_token_id
+    engine.reset()
+    h = engine.prefill(embeds, select="greedy", return_hidden=True)
+    hidden = [ops.rmsnorm(h[-1:], engine.final_norm, engine.eps)]
+    n = 1
+    while n < max_new_tokens and not int(engine.done[0].item()):
+        engine._layers_step()
+        hidden.append(ops.rmsnorm(engine.x[:1].clone(), engine.final_norm, engine.eps))
+        engine._logits_and_commit(greedy=True)
+        n += 1
+    return {"tokens": _emitted(engine)[:n], "hidden": torch.cat(hidden)[:n]}

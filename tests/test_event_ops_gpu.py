@@ -1,0 +1,57 @@
+"""GPU event front end vs the numpy implementation."""
+import numpy as np
+import pytest
+import torch
+
+from eventgpt_amd.data import clip_preprocess as cp
+from eventgpt_amd.data.events import (polarity_histogram, rasterize, slice_bounds_by_count,
+                                      synthetic_events, voxel_grid)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("conflict", ["last", "negative"])
+def test_raster_matches_numpy(dev, conflict):
+    from eventgpt_amd.ops import event_ops as eo
+    ev = synthetic_events(50_000, 160, 120, seed=4)
+    d = eo.events_to_device(ev, dev)
+    img = eo.rasterize_gpu(d, 5, (120, 160), conflict).cpu().numpy()
+    for i, (a, b) in enumerate(slice_bounds_by_count(50_000, 5)):
+        want = rasterize(ev["x"][a:b], ev["y"][a:b], ev["p"][a:b], size=(120, 160), conflict=conflict)
+        assert np.array_equal(img[i], want), i
+
+
+def test_voxel_and_histogram_match_numpy(dev):
+    from eventgpt_amd.ops import event_ops as eo
+    ev = synthetic_events(30_000, 64, 48, seed=2)
+    d = eo.events_to_device(ev, dev)
+    hist, vox = eo.voxel_grid_gpu(d, 5, (48, 64))
+    assert np.array_equal(hist.cpu().numpy(), polarity_histogram(ev, 5, (48, 64)))
+    assert np.allclose(vox.cpu().numpy(), voxel_grid(ev, 5, (48, 64)))
+    _, voxc = eo.voxel_grid_gpu(d, 5, (48, 64), signed=False, by="count")
+    assert np.allclose(voxc.cpu().numpy(), voxel_grid(ev, 5, (48, 64), signed=False, by="count"))
+
+
+@pytest.mark.parametrize("hw", [(480, 640), (120, 160), (336, 336), (400, 300)])
+def test_clip_preprocess_matches_host(dev, hw):
+    from eventgpt_amd.ops import event_ops as eo
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 256, (2, hw[0], hw[1], 3), dtype=np.uint8)
+    got = eo.clip_preprocess_gpu(torch.from_numpy(frames).to(dev)).float().cpu()
+    want = torch.stack([torch.from_numpy(cp.preprocess_image(f)) for f in frames])
+    assert got.shape == (2, 3, 336, 336)
+    # bf16 output: compare after the same rounding
+    assert torch.equal(got, want.to(torch.bfloat16).float())
+
+
+def test_event_frames_gpu_end_to_end(dev):
+    from eventgpt_amd.ops import event_ops as eo
+    from eventgpt_amd.data.events import event_frames
+    ev = synthetic_events(60_000, 640, 480, seed=9)
+    size, px = eo.event_frames_gpu(ev, dev, 5)
+    assert size == [480, 640] and px.shape == (5, 3, 336, 336) and px.dtype == torch.bfloat16
+    host = event_frames(ev, 5)
+    same_canvas = [f for f in host if f.shape[:2] == (480, 640)]
+    if len(same_canvas) == 5:
+        want = torch.stack([torch.from_numpy(cp.preprocess_image(f)) for f in host])
+        assert torch.equal(px.float().cpu(), want.to(torch.bfloat16).float())
