@@ -278,6 +278,17 @@ void decode_gemv_residual(const Tensor& w, const Tensor& xin, const Tensor& y) {
                      (int)N, (int)K, cur_stream());
 }
 
+// y = W @ xin (+ y when accumulate).  Tensor-parallel row-parallel projections
+// use accumulate on rank 0 only, so the all-reduce that follows adds the residual once.
+void decode_gemv(const Tensor& w, const Tensor& xin, const Tensor& y, bool accumulate) {
+  check_bf16(w, "w"); check_bf16(xin, "xin"); check_bf16(y, "y");
+  const int64_t B = xin.size(0), K = xin.size(1), N = w.size(0);
+  TORCH_CHECK(xin.dim() == 2 && w.size(1) == K && y.numel() == B * N && N % 4 == 0 && K % 8 == 0);
+  TORCH_CHECK(B <= evgpt::gemv_max_batch() && B * K * 2 <= 96 * 1024);
+  evgpt::launch_gemv(bptr(w), bptr(xin), bptr_mut(y), nullptr, accumulate ? bptr(y) : nullptr,
+                     nullptr, 0.f, 0, (int)B, (int)N, (int)K, cur_stream());
+}
+
 // h = silu(Wg rmsnorm(x)) * (Wu rmsnorm(x));  w_gate_up [2I,K] = [gate rows | up rows]
 void decode_mlp_up(const Tensor& w_gate_up, const Tensor& x, const Tensor& norm_w, double eps,
                    const Tensor& h) {
@@ -514,6 +525,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("decode_qkv(Tensor x, Tensor norm_w, Tensor w_qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos, float eps, int Hq, int Hkv, int D) -> ()", &decode_qkv);
   m.def("decode_attn(Tensor q, Tensor k_cache, Tensor v_cache, Tensor(a!) out, Tensor(b!) part_o, Tensor(c!) part_ml, Tensor pos, int nsplit, float scale) -> ()", &decode_attn);
   m.def("decode_gemv_residual(Tensor w, Tensor xin, Tensor(a!) y) -> ()", &decode_gemv_residual);
+  m.def("decode_gemv(Tensor w, Tensor xin, Tensor(a!) y, bool accumulate) -> ()", &decode_gemv);
   m.def("decode_mlp_up(Tensor w_gate_up, Tensor x, Tensor norm_w, float eps, Tensor(a!) h) -> ()", &decode_mlp_up);
   m.def("logits_partials(int N) -> int", &logits_partials);
   m.def("decode_logits(Tensor w, Tensor x, Tensor? norm_w, float eps, Tensor(a!)? logits, Tensor(b!) part_val, Tensor(c!) part_idx) -> ()", &decode_logits);

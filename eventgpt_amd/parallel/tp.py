@@ -1,0 +1,314 @@
+"""Tensor parallelism for the LLaMA decoder (Megatron-style 1-D sharding).
+
+Sharding over W ranks (one process per GPU, RCCL over xGMI):
+
+    q/k/v     column-parallel by head     rank r owns heads [r*Hq/W, (r+1)*Hq/W)
+    o_proj    row-parallel                input columns of those heads
+    gate/up   column-parallel             I/W intermediate columns (zero-padded to x64)
+    down      row-parallel
+    lm_head   vocab-parallel              ceil(V/W) rows; greedy needs only (max, idx)
+    norms, embeddings                     replicated
+
+Each layer costs two all-reduces of ``[B, S, H]``.  The residual add is folded
+into them: rank 0 accumulates its partial product onto the residual stream,
+the other ranks overwrite theirs, and the sum of all ranks' buffers is the new
+residual — no extra pass over the activations.
+
+Two executions of the same sharding:
+  * ``TensorParallelDecoder`` — nn.Module path through ``eventgpt_amd.ops``; runs
+    anywhere (CPU + gloo in the tests) and is the correctness oracle;
+  * ``TensorParallelEngine`` — the serving engine (``runtime.engine``) on shards:
+    fused GEMV kernels for batch <= 4, MFMA GEMM (split-K for M <= 32) for the
+    bs=32 batched-decode configuration, static KV cache of the local heads,
+    greedy token selection by gathering per-rank argmax partials.
+
+The reference has no model parallelism (its only process group is a
+world-size-1 NCCL init demanded by a third-party model,
+feasible_imu/benchmark_onellm_5stages.py:393-406).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .. import ops
+from ..runtime.engine import GenerationEngine, _Layer
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def shard_layer(lyr, rank: int, world: int, hq: int, hkv: int, d: int, inter: int,
+                pad_to: int = 64):
+    """Weight shards of one decoder layer for ``rank``.
+
+    Returns ``(w_qkv [(hq_l+2hkv_l)*d, H], w_o [H, hq_l*d], w_gate_up [2*I_l, H],
+    w_down [H, I_l])`` with ``I_l`` zero-padded to a multiple of ``pad_to``.
+    """
+    if hq % world or hkv % world:
+        raise ValueError(f"heads ({hq}/{hkv}) must divide by the TP degree {world}")
+    hq_l, hkv_l = hq // world, hkv // world
+    at, mlp = lyr.self_attn, lyr.mlp
+    q = at.q_proj.weight.data[rank * hq_l * d:(rank + 1) * hq_l * d]
+    k = at.k_proj.weight.data[rank * hkv_l * d:(rank + 1) * hkv_l * d]
+    v = at.v_proj.weight.data[rank * hkv_l * d:(rank + 1) * hkv_l * d]
+    w_qkv = torch.cat([q, k, v]).contiguous()
+    w_o = at.o_proj.weight.data[:, rank * hq_l * d:(rank + 1) * hq_l * d].contiguous()
+    per = (inter + world - 1) // world
+    lo, hi = rank * per, min((rank + 1) * per, inter)
+    i_l = _round_up(per, pad_to)
+    h = mlp.gate_proj.weight.shape[1]
+    w_gu = mlp.gate_proj.weight.data.new_zeros(2 * i_l, h)
+    w_gu[:hi - lo] = mlp.gate_proj.weight.data[lo:hi]
+    w_gu[i_l:i_l + hi - lo] = mlp.up_proj.weight.data[lo:hi]
+    w_down = mlp.down_proj.weight.data.new_zeros(h, i_l)
+    w_down[:, :hi - lo] = mlp.down_proj.weight.data[:, lo:hi]
+    return w_qkv, w_o, w_gu, w_down
+
+
+def shard_vocab(weight: torch.Tensor, rank: int, world: int) -> Tuple[torch.Tensor, int]:
+    """``(rows [ceil(V/W), H] zero-padded, first_row)`` of a vocab-parallel matrix."""
+    v = weight.shape[0]
+    per = (v + world - 1) // world
+    lo, hi = rank * per, min((rank + 1) * per, v)
+    out = weight.new_zeros(per, weight.shape[1])
+    if hi > lo:
+        out[:hi - lo] = weight[lo:hi]
+    return out, lo
+
+
+def _all_reduce(t: torch.Tensor, group) -> torch.Tensor:
+    if group is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if dist.get_backend(group) == "gloo" and t.is_cuda:   # gloo only ever sees host tensors
+        host = t.cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+        return t
+    dist.all_reduce(t, group=group)
+    return t
+
+
+def distributed_argmax(local_val: torch.Tensor, local_idx: torch.Tensor, group) -> torch.Tensor:
+    """Global argmax from per-rank ``(max value, global index)`` pairs ``[B]``; ties go to
+    the lowest index.  Only 8 bytes per row per rank cross the fabric."""
+    world = dist.get_world_size(group) if (group is not None and dist.is_initialized()) else 1
+    if world == 1:
+        return local_idx
+    pack = torch.stack([local_val.float(), local_idx.float()], dim=-1).contiguous()
+    if dist.get_backend(group) == "gloo" and pack.is_cuda:
+        host = pack.cpu()
+        bufs = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(bufs, host, group=group)
+        allp = torch.stack(bufs).to(pack.device)
+    else:
+        allp = torch.empty(world, *pack.shape, dtype=pack.dtype, device=pack.device)
+        dist.all_gather_into_tensor(allp.view(-1, pack.shape[-1]), pack.view(-1, pack.shape[-1]),
+                                    group=group)
+    vals, idxs = allp[..., 0], allp[..., 1]                # [W, B]
+    best = vals.max(dim=0, keepdim=True).values
+    cand = torch.where(vals == best, idxs, torch.full_like(idxs, float("inf")))
+    return cand.min(dim=0).values.long()
+
+
+# ------------------------------------------------------------------ module path
+class TensorParallelDecoder(nn.Module):
+    """The sharded decoder evaluated through ``eventgpt_amd.ops`` (any device)."""
+
+    def __init__(self, model, group=None):
+        super().__init__()
+        cfg = model.config
+        self.cfg, self.group = cfg, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.hq_l = cfg.num_attention_heads // self.world
+        self.hkv_l = cfg.num_key_value_heads // self.world
+        self.d = cfg.head_dim
+        self.shards = [shard_layer(l, self.rank, self.world, cfg.num_attention_heads,
+                                   cfg.num_key_value_heads, self.d, cfg.intermediate_size)
+                       for l in model.model.layers]
+        self.norms = [(l.input_layernorm.weight.data, l.post_attention_layernorm.weight.data)
+                      for l in model.model.layers]
+        self.final_norm = model.model.norm.weight.data
+        self.lm_head, self.v0 = shard_vocab(model.lm_head.weight.data, self.rank, self.world)
+        self.v_total = model.lm_head.weight.shape[0]
+        self.rope = model.model.rope(model.device)
+        self.eps = cfg.rms_norm_eps
+
+    @torch.no_grad()
+    def forward(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
+        """``[B, S, H]`` -> final-norm hidden states ``[B, S, H]`` (identical on all ranks)."""
+        x = inputs_embeds
+        b, s, _ = x.shape
+        pos = torch.arange(s, device=x.device)[None].expand(b, s)
+        cos, sin = self.rope
+        nq, nk = self.hq_l * self.d, self.hkv_l * self.d
+        for (w_qkv, w_o, w_gu, w_down), (n1, n2) in zip(self.shards, self.norms):
+            qkv = ops.linear(ops.rmsnorm(x, n1, self.eps), w_qkv)
+            q = ops.apply_rope(qkv[..., :nq].reshape(b, s, self.hq_l, self.d), pos, cos, sin)
+            k = ops.apply_rope(qkv[..., nq:nq + nk].reshape(b, s, self.hkv_l, self.d), pos, cos, sin)
+            v = qkv[..., nq + nk:].reshape(b, s, self.hkv_l, self.d)
+            if self.hkv_l != self.hq_l:
+                rep = self.hq_l // self.hkv_l
+                k, v = k.repeat_interleave(rep, 2), v.repeat_interleave(rep, 2)
+            o = ops.attention(q.contiguous(), k.contiguous(), v.contiguous(), causal=True)
+            part = ops.linear(o.reshape(b, s, nq), w_o, residual=x if self.rank == 0 else None)
+            x = _all_reduce(part, self.group)
+            h = ops.swiglu(ops.linear(ops.rmsnorm(x, n2, self.eps), w_gu))
+            part = ops.linear(h, w_down, residual=x if self.rank == 0 else None)
+            x = _all_reduce(part, self.group)
+        return ops.rmsnorm(x, self.final_norm, self.eps)
+
+    @torch.no_grad()
+    def greedy_next(self, hidden_last: torch.Tensor) -> torch.Tensor:
+        """Greedy token per row of ``hidden_last [B, H]`` via the vocab-parallel head."""
+        logits = ops.linear(hidden_last, self.lm_head).float()
+        n_valid = min(self.lm_head.shape[0], max(self.v_total - self.v0, 0))
+        logits[:, n_valid:] = float("-inf")
+        val, idx = logits.max(dim=-1)
+        return distributed_argmax(val, idx + self.v0, self.group)
+
+
+# ------------------------------------------------------------------- engine path
+class TensorParallelEngine(GenerationEngine):
+    """``GenerationEngine`` over weight shards, for any batch size.
+
+    ``group=None`` (or a world of one) gives the plain batched engine — the same
+    code path minus the collectives — which is how it is exercised on one GPU.
+    """
+
+    def __init__(self, model, group=None, max_len: int = 2048, max_batch: int = 1, **kw):
+        self._group_arg = group
+        super().__init__(model, max_len=max_len, max_batch=max_batch, **kw)
+
+    def _setup_parallel(self) -> None:
+        g = self._group_arg
+        if g is not None and dist.is_initialized() and dist.get_world_size(g) > 1:
+            self.tp_group, self.tp_world, self.tp_rank = g, dist.get_world_size(g), dist.get_rank(g)
+        cfg = self.cfg
+        self.Hq_full, self.Hkv_full, self.I_full = self.Hq, self.Hkv, self.I
+        self.Hq //= self.tp_world
+        self.Hkv //= self.tp_world
+        self.I = _round_up((self.I_full + self.tp_world - 1) // self.tp_world, 64)
+
+    def _pack_weights(self, model) -> None:
+        bf = dict(dtype=torch.bfloat16, device=self.device)
+        for lyr in model.model.layers:
+            w_qkv, w_o, w_gu, w_down = shard_layer(lyr, self.tp_rank, self.tp_world, self.Hq_full,
+                                                   self.Hkv_full, self.D, self.I_full)
+            self.layers.append(_Layer(
+                w_qkv, w_o, w_gu, w_down, lyr.input_layernorm.weight.data,
+                lyr.post_attention_layernorm.weight.data,
+                torch.zeros(self.B, self.Hkv, self.l_max, self.D, **bf),
+                torch.zeros(self.B, self.Hkv, self.l_max, self.D, **bf)))
+            if self.tp_world > 1:       # the full matrices are no longer needed on this rank
+                for p in lyr.parameters():
+                    if p.ndim == 2:
+                        p.data = p.data.new_empty(0)
+        self.final_norm = model.model.norm.weight.data
+        self.lm_head, self.v0 = shard_vocab(model.lm_head.weight.data, self.tp_rank, self.tp_world)
+        self.v_total = model.lm_head.weight.shape[0]
+        self.embed = model.model.embed_tokens.weight.data
+
+    # ------------------------------------------------------------------ layers
+    def _reduce(self, t: torch.Tensor) -> torch.Tensor:
+        return _all_reduce(t, self.tp_group)
+
+    def _forward_rows(self, embeds, batch, pos0):
+        raw = self.raw
+        S = embeds.shape[0]
+        x = embeds.to(torch.bfloat16).contiguous().view(1, S, self.H)
+        kv_len = pos0 + S
+        q = torch.empty(1, S, self.Hq, self.D, dtype=torch.bfloat16, device=self.device)
+        o = torch.empty_like(q)
+        lead = self.tp_rank == 0
+        for l in self.layers:
+            kc, vc = l.k_cache[batch:batch + 1], l.v_cache[batch:batch + 1]
+            qkv = raw.linear(raw.rmsnorm(x, l.norm1, self.eps), l.w_qkv, None, None, 0, False)
+            raw.prefill_rope_kv(qkv, q, kc, vc, self.cos, self.sin, pos0, self.Hq, self.Hkv, self.D)
+            raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
+            x = self._reduce(raw.linear(o.view(1, S, self.Hq * self.D), l.w_o, None,
+                                        x if lead else None, 0, False))
+            gu = raw.linear(raw.rmsnorm(x, l.norm2, self.eps), l.w_gate_up, None, None, 0, False)
+            x = self._reduce(raw.linear(raw.swiglu(gu), l.w_down, None, x if lead else None, 0, False))
+        return x
+
+    def _layers_step(self) -> None:
+        raw = self.raw
+        lead = self.tp_rank == 0
+        if self.B <= 4:
+            for l in self.layers:
+                raw.decode_qkv(self.x, l.norm1, l.w_qkv, self.q, l.k_cache, l.v_cache, self.cos,
+                               self.sin, self.pos, self.eps, self.Hq, self.Hkv, self.D)
+                raw.decode_attn(self.q, l.k_cache, l.v_cache, self.attn, self.part_o, self.part_ml,
+                                self.pos, self.nsplit, self.scale)
+                raw.decode_gemv(l.w_o, self.attn, self.x, lead)
+                self._reduce(self.x)
+                raw.decode_mlp_up(l.w_gate_up, self.x, l.norm2, self.eps, self.h)
+                raw.decode_gemv(l.w_down, self.h, self.x, lead)
+                self._reduce(self.x)
+            return
+        # batched decode (e.g. 32 streams): M = B rows through the MFMA GEMM
+        B = self.B
+        x = self.x
+        for l in self.layers:
+            qkv = raw.linear(raw.rmsnorm(x, l.norm1, self.eps), l.w_qkv, None, None, 0, False)
+            raw.prefill_rope_kv(qkv.view(B, 1, -1), self.q.view(B, 1, -1), l.k_cache, l.v_cache,
+                                self.cos, self.sin, self.pos, self.Hq, self.Hkv, self.D)
+            raw.decode_attn(self.q, l.k_cache, l.v_cache, self.attn, self.part_o, self.part_ml,
+                            self.pos, self.nsplit, self.scale)
+            x = self._reduce(raw.linear(self.attn, l.w_o, None, x if lead else None, 0, False))
+            gu = raw.linear(raw.rmsnorm(x, l.norm2, self.eps), l.w_gate_up, None, None, 0, False)
+            x = self._reduce(raw.linear(raw.swiglu(gu), l.w_down, None, x if lead else None, 0, False))
+        self.x.copy_(x)
+
+    def _logits_and_commit(self, greedy: bool, want_logits: bool = False) -> None:
+        raw = self.raw
+        hn = raw.rmsnorm(self.x, self.final_norm, self.eps)
+        logits = raw.linear(hn, self.lm_head, None, None, 0, True)          # fp32 [B, V_local]
+        n_valid = min(self.lm_head.shape[0], max(self.v_total - self.v0, 0))
+        if n_valid < logits.shape[1]:
+            logits[:, n_valid:] = float("-inf")
+        if not greedy or want_logits:
+            if self.tp_world > 1:
+                raise NotImplementedError("sampling needs the full logits; gather them first")
+            self.logits.copy_(logits[:, :self.logits.shape[1]])
+        if greedy:
+            # own argmax kernel + gather: graph-safe (no library reduction in the capture)
+            idx = raw.argmax_rows(logits)
+            val = logits.gather(1, idx[:, None])[:, 0]
+            tok = distributed_argmax(val, idx + self.v0, self.tp_group)
+            self.sampled.copy_(tok.to(torch.int32))
+            self._commit_sampled()
+
+    # ----------------------------------------------------------------- batching
+    @torch.no_grad()
+    def prefill_batch(self, embeds_list: Sequence[torch.Tensor]) -> None:
+        """Prefill sequence ``b`` with ``embeds_list[b]`` for every slot, then pick and
+        commit the first token of all of them in one step."""
+        if len(embeds_list) != self.B:
+            raise ValueError(f"need {self.B} prompts, got {len(embeds_list)}")
+        self.reset()
+        for b, emb in enumerate(embeds_list):
+            pos0 = torch.zeros(1, dtype=torch.int32, device=self.device)
+            h = self._forward_rows(emb, b, pos0)
+            self.x[b].copy_(h[0, -1])
+            self.pos[b] = emb.shape[0] - 1      # the commit advances it to the prompt length
+        self._logits_and_commit(greedy=True)
+
+    def prefill(self, embeds, batch: int = 0, start: Optional[int] = None,
+                select: Optional[str] = "greedy", return_hidden: bool = False):
+        if self.B == 1:
+            return super().prefill(embeds, batch, start, select, return_hidden)
+        if select is not None:
+            raise ValueError("with several sequences use prefill_batch (one commit for all)")
+        return super().prefill(embeds, batch, start, None, return_hidden)
+
+    def tokens(self, batch: int) -> torch.Tensor:
+        n = int(self.step[batch].item())
+        return self.out_tokens[batch, :n].to(torch.long)

@@ -71,7 +71,6 @@ class GenerationEngine:
         self.Hkv = cfg.num_key_value_heads
         self.D = cfg.head_dim
         self.I = cfg.intermediate_size
-        self.V = model.lm_head.weight.shape[0]
         self.eps = float(cfg.rms_norm_eps)
         self.l_max = max_len
         self.nsplit = nsplit
@@ -84,32 +83,16 @@ class GenerationEngine:
         if self.H % 64 or self.I % 8:
             raise ValueError("hidden size must be a multiple of 64, intermediate of 8")
 
+        self.tp_world, self.tp_rank, self.tp_group = 1, 0, None
+        self._setup_parallel()
         self.layers: List[_Layer] = []
-        bf = dict(dtype=torch.bfloat16, device=dev)
-        with torch.no_grad():
-            for lyr in model.model.layers:
-                at, mlp = lyr.self_attn, lyr.mlp
-                w_qkv = torch.cat([at.q_proj.weight.data, at.k_proj.weight.data,
-                                   at.v_proj.weight.data]).contiguous()
-                nq, nk = self.Hq * self.D, self.Hkv * self.D
-                at.q_proj.weight.data = w_qkv[:nq]
-                at.k_proj.weight.data = w_qkv[nq:nq + nk]
-                at.v_proj.weight.data = w_qkv[nq + nk:]
-                w_gu = torch.cat([mlp.gate_proj.weight.data, mlp.up_proj.weight.data]).contiguous()
-                mlp.gate_proj.weight.data = w_gu[:self.I]
-                mlp.up_proj.weight.data = w_gu[self.I:]
-                self.layers.append(_Layer(
-                    w_qkv, at.o_proj.weight.data, w_gu, mlp.down_proj.weight.data,
-                    lyr.input_layernorm.weight.data, lyr.post_attention_layernorm.weight.data,
-                    torch.zeros(self.B, self.Hkv, max_len, self.D, **bf),
-                    torch.zeros(self.B, self.Hkv, max_len, self.D, **bf)))
-        self.final_norm = model.model.norm.weight.data
-        self.lm_head = model.lm_head.weight.data
-        self.embed = model.model.embed_tokens.weight.data
+        self._pack_weights(model)
+        self.V = self.lm_head.shape[0]
         cos, sin = ops.rope_tables(max_len, self.D, cfg.rope_theta, dev)
         self.cos, self.sin = cos.contiguous(), sin.contiguous()
 
         B = self.B
+        bf = dict(dtype=torch.bfloat16, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         self.x = torch.zeros(B, self.H, **bf)           # residual stream of the decode step
@@ -132,6 +115,35 @@ class GenerationEngine:
         self.eos = int(cfg.eos_token_id if cfg.eos_token_id is not None else -1)
         self._graph_greedy = None
         self._graph_logits = None
+
+    # ---------------------------------------------------------------- weights
+    def _setup_parallel(self) -> None:
+        """Hook for tensor-parallel subclasses (sets tp_* and local head counts)."""
+
+    def _pack_weights(self, model) -> None:
+        """Pack ``q|k|v`` and ``gate|up`` rows and allocate the KV cache.  The module's
+        parameters are re-pointed at views of the packed storage (one copy in HBM)."""
+        bf = dict(dtype=torch.bfloat16, device=self.device)
+        with torch.no_grad():
+            for lyr in model.model.layers:
+                at, mlp = lyr.self_attn, lyr.mlp
+                w_qkv = torch.cat([at.q_proj.weight.data, at.k_proj.weight.data,
+                                   at.v_proj.weight.data]).contiguous()
+                nq, nk = self.Hq * self.D, self.Hkv * self.D
+                at.q_proj.weight.data = w_qkv[:nq]
+                at.k_proj.weight.data = w_qkv[nq:nq + nk]
+                at.v_proj.weight.data = w_qkv[nq + nk:]
+                w_gu = torch.cat([mlp.gate_proj.weight.data, mlp.up_proj.weight.data]).contiguous()
+                mlp.gate_proj.weight.data = w_gu[:self.I]
+                mlp.up_proj.weight.data = w_gu[self.I:]
+                self.layers.append(_Layer(
+                    w_qkv, at.o_proj.weight.data, w_gu, mlp.down_proj.weight.data,
+                    lyr.input_layernorm.weight.data, lyr.post_attention_layernorm.weight.data,
+                    torch.zeros(self.B, self.Hkv, self.l_max, self.D, **bf),
+                    torch.zeros(self.B, self.Hkv, self.l_max, self.D, **bf)))
+        self.final_norm = model.model.norm.weight.data
+        self.lm_head = model.lm_head.weight.data
+        self.embed = model.model.embed_tokens.weight.data
 
     # ------------------------------------------------------------------ state
     def reset(self) -> None:

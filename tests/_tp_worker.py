@@ -1,0 +1,38 @@
+"""Worker for the tensor-parallel test: sharded decoder on gloo vs the full model."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eventgpt_amd.models import EventChatConfig, EventChatModel  # noqa: E402
+from eventgpt_amd.parallel.dist import init_distributed, shutdown  # noqa: E402
+from eventgpt_amd.parallel.tp import TensorParallelDecoder  # noqa: E402
+
+
+def main(out_path):
+    info = init_distributed(use_gpu=False)
+    cfg = EventChatConfig(vocab_size=203, hidden_size=64, intermediate_size=172,
+                          num_hidden_layers=2, num_attention_heads=4, max_position_embeddings=128,
+                          torch_dtype="float32")
+    model = EventChatModel.from_config(cfg, torch.float32, "cpu", seed=5)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 9, 64, generator=g)
+    full = model.model(inputs_embeds=x).last_hidden_state
+    full_tok = model.lm_head(full[:, -1]).argmax(-1)
+    tp = TensorParallelDecoder(model, dist.group.WORLD)
+    h = tp(x)
+    tok = tp.greedy_next(h[:, -1])
+    err = (h - full).abs().max().item()
+    gathered = [None] * info.world
+    dist.all_gather_object(gathered, {"err": err, "tok": tok.tolist()})
+    if info.rank == 0:
+        json.dump({"ranks": gathered, "want_tok": full_tok.tolist(),
+                   "i_local": tp.shards[0][2].shape[0] // 2}, open(out_path, "w"))
+    shutdown()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -110,3 +110,23 @@ def test_vision_engine_matches_module_path(dev):
     assert err < 0.06, err
     one = m.vision_engine().encode(frames[:1])
     assert one.shape == (1 + 17, 512)
+
+
+@pytest.mark.parametrize("B", [3, 6])
+def test_batched_engine_matches_single_stream(model, dev, B):
+    """TensorParallelEngine with a world of one = the batched decode path (GEMV for
+    B <= 4, MFMA GEMM above); every stream must reproduce its own greedy decode."""
+    from eventgpt_amd.parallel.tp import TensorParallelEngine
+    prompts = [(torch.randn(20 + 3 * b, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(b))
+                * 0.5).to(torch.bfloat16) for b in range(B)]
+    single = model.engine(max_len=512, max_new_tokens=64)
+    want = [single.generate(p, 10, eos_token_id=-1) for p in prompts]
+    eng = TensorParallelEngine(model, None, max_len=256, max_batch=B, max_new_tokens=32)
+    eng.eos = -1
+    eng.prefill_batch(prompts)
+    for _ in range(9):
+        eng.decode_step(True)
+    for b in range(B):
+        got = eng.tokens(b)
+        same = (got == want[b]).long().cumprod(0).sum().item()
+        assert same >= 6, (b, got.tolist(), want[b].tolist())
