@@ -27,11 +27,16 @@ from ..ops.hip import ACT_CODES
 
 
 class VisionEngine:
-    def __init__(self, model, use_graph: bool = True):
+    def __init__(self, model, use_graph: bool = True, tower=None, projector=None,
+                 adaptor="auto", feature_layer: int = -1):
+        """``tower``/``projector``/``adaptor`` default to the EventChat modules of
+        ``model``; a video verifier passes its own.  ``feature_layer`` follows the
+        HF ``hidden_states`` convention (-1 = after the last block, -2 = skip it)."""
         from ..ops import hip
         self.raw = hip.raw
         self.model = model
-        tower = model.get_visual_tower().visual_tower
+        if tower is None:
+            tower = model.get_visual_tower().visual_tower
         self.cfg = tower.config
         vm = tower.vision_model
         self.device = model.device
@@ -72,9 +77,14 @@ class VisionEngine:
                     ln2=(lyr.layer_norm2.weight.data, lyr.layer_norm2.bias.data),
                     w1=lyr.mlp.fc1.weight.data, b1=lyr.mlp.fc1.bias.data,
                     w2=lyr.mlp.fc2.weight.data, b2=lyr.mlp.fc2.bias.data))
-        proj = model.get_model().visual_projector
-        self.proj = [(m.weight.data, m.bias.data) for m in proj if hasattr(m, "weight")]
-        fa = getattr(model.get_model(), "feature_adaptor", None)
+        n_run = len(self.layers) + 1 + feature_layer if feature_layer < 0 else feature_layer
+        if not 0 < n_run <= len(self.layers):
+            raise ValueError(f"feature_layer {feature_layer} outside the tower's {len(self.layers)} blocks")
+        self.layers = self.layers[:n_run]
+        proj = model.get_model().visual_projector if projector is None else projector
+        mods = proj if isinstance(proj, (list, tuple, torch.nn.Sequential)) else proj.children()
+        self.proj = [(m.weight.data, m.bias.data) for m in mods if hasattr(m, "weight")]
+        fa = getattr(model.get_model(), "feature_adaptor", None) if adaptor == "auto" else adaptor
         self.adaptor = (fa.weight.data, fa.bias.data) if fa is not None else None
         self._graphs: Dict[tuple, tuple] = {}
 
