@@ -1,0 +1,42 @@
+"""Time the speculative-decoding verify pass (G draft rows in one forward) against a
+plain decode step on the 7B decoder.  ``python benchmarks/bench_verify.py [G] [prompt_len]``"""
+import sys
+import time
+
+import torch
+
+from eventgpt_amd.models import EventChatConfig, EventChatModel
+
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 2115
+dev = torch.device("cuda")
+cfg = EventChatConfig.eventgpt_7b()
+cfg.num_hidden_layers = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+model = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=0)
+eng = model.engine(max_len=4096)
+eng.eos = -1
+emb = (torch.randn(L, cfg.hidden_size, device=dev) * 0.02).to(torch.bfloat16)
+eng.reset()
+eng.prefill(emb, select="greedy")
+draft = torch.randint(0, 32000, (G,), device=dev, dtype=torch.int32)
+
+
+def timeit(fn, n=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+t_dec = timeit(lambda: eng.decode_step(True))
+eng.pos.fill_(L); eng.step.fill_(1)
+def ver():
+    eng.pos.fill_(L); eng.step.fill_(1)
+    eng.verify(draft, G)
+t_ver = timeit(ver)
+print(f"layers={cfg.num_hidden_layers} kv_len={L} decode_step={t_dec:.3f} ms  verify(G={G})={t_ver:.3f} ms  "
+      f"ratio={t_ver / t_dec:.2f}", flush=True)

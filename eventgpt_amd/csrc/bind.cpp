@@ -193,9 +193,19 @@ void attention_cache(const Tensor& q, const Tensor& k_cache, const Tensor& v_cac
   TORCH_CHECK(kv_len.numel() == B && (D == 64 || D == 128) && Hq % Hkv == 0);
   long long s[12] = {Sq * Hq * D, Hq * D, D, Hkv * Lmax * D, D, Lmax * D,
                      Hkv * Lmax * D, D, Lmax * D, Sq * Hq * D, Hq * D, D};
+  // a handful of query rows against a long cache (speculative verify): one block
+  // per head would stream the whole cache serially, so split the keys over blocks
+  const int nsplit = (Sq <= 64 && Lmax >= 512) ? 16 : 0;
+  Tensor part_o, part_ml;
+  if (nsplit > 0) {
+    part_o = at::empty({B, Hq, nsplit, Sq, D}, q.options().dtype(at::kFloat));
+    part_ml = at::empty({B, Hq, nsplit, Sq, 2}, q.options().dtype(at::kFloat));
+  }
   evgpt::launch_attn_prefill(bptr(q), bptr(k_cache), bptr(v_cache), bptr_mut(out), s,
                              kv_len.data_ptr<int>(), (int)B, (int)Sq, (int)Lmax, (int)Hq, (int)Hkv,
-                             (int)D, 1, 0, 1, (float)scale, cur_stream());
+                             (int)D, 1, 0, 1, (float)scale, cur_stream(),
+                             nsplit ? part_o.data_ptr<float>() : nullptr,
+                             nsplit ? part_ml.data_ptr<float>() : nullptr, nsplit);
 }
 
 Tensor st_pool(const Tensor& f, int64_t n_temporal) {

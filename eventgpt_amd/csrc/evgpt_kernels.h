@@ -88,6 +88,7 @@ void launch_attn_decode(const bf16_t* q, const bf16_t* k_cache, const bf16_t* v_
 void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o,
                          const long long* strides, const int* kv_len, int B, int Sq, int Sk,
                          int Hq, int Hkv, int D, int causal, int q_offset, int q_offset_from_len,
-                         float scale, hipStream_t st);
+                         float scale, hipStream_t st, float* part_o = nullptr,
+                         float* part_ml = nullptr, int nsplit = 0);
 
 }  // namespace evgpt

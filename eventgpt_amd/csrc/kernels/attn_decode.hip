@@ -26,7 +26,8 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_split_kernel(
   const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z, nsplit = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int sub = lane / LPK, dl = lane % LPK;
-  const int len = pos[b] + 1;  // the current token's K/V were appended by the QKV kernel
+  // the current token's K/V were appended by the QKV kernel; never read past the cache
+  const int len = min(max(pos[b] + 1, 1), l_max);
   const int hk = h / (Hq / Hkv);
 
   // this split's key range, in units of KPW-key groups

@@ -34,6 +34,10 @@ struct AttnParams {
   int q_offset;                 // absolute position of query row 0 minus key 0 (causal)
   int q_offset_from_len;        // if set: q_offset = kv_len[b] - Sq
   float scale_log2e;
+  // split-KV mode (few query rows against a long cache): block x = key split
+  float* part_o;                // [B][Hq][nsplit][Sq][D] unnormalised fp32
+  float* part_ml;               // [B][Hq][nsplit][Sq][2] (running max in log2 units, sum)
+  int nsplit;
 };
 
 constexpr int TK = 64;  // keys per tile
@@ -48,7 +52,7 @@ __device__ __forceinline__ int tile_off(int row, int ch) {
   return row * (D * 2) + ((ch ^ swz<D>(row)) << 4);
 }
 
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool SPLIT = false>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
   constexpr int CPR = D / 8;                  // 16-byte chunks per row
   constexpr int TILE_BYTES = TK * D * 2;
@@ -63,9 +67,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
   const int fr = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.Hq / p.Hkv);
-  const int Sk = p.kv_len ? p.kv_len[b] : p.Sk;
+  // a device-side key count can never address past the buffer capacity p.Sk
+  int Sk = p.kv_len ? p.kv_len[b] : p.Sk;
+  Sk = Sk > p.Sk ? p.Sk : (Sk < 0 ? 0 : Sk);
   const int q_off = p.q_offset_from_len ? (Sk - p.Sq) : p.q_offset;
-  const int qb0 = blockIdx.x * 64;           // first query row of the block
+  const int qb0 = SPLIT ? 0 : blockIdx.x * 64;  // first query row of the block
   const int qi = qb0 + wid * 16 + fr;        // this lane's query row
   const int qi_c = qi < p.Sq ? qi : p.Sq - 1;
 
@@ -87,7 +93,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     const int last_q = min(qb0 + 63, p.Sq - 1);
     k_end = min(Sk, last_q + q_off + 1);
   }
-  const int ntiles = (k_end + TK - 1) / TK;
+  int ntiles = (k_end + TK - 1) / TK;
+  int t_begin = 0;
+  if (SPLIT) {
+    const int per = (ntiles + p.nsplit - 1) / p.nsplit;
+    t_begin = min(static_cast<int>(blockIdx.x) * per, ntiles);
+    ntiles = min(t_begin + per, ntiles);
+  }
+  // waves whose 16 query rows are all padding only help staging the tiles
+  const bool wave_active = qb0 + wid * 16 < p.Sq;
 
   u32x4_t kreg[LD_PER_THREAD], vreg[LD_PER_THREAD];
   auto prefetch = [&](int t) {
@@ -115,12 +129,13 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
   for (int i = 0; i < DT; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;
 
-  if (ntiles > 0) prefetch(0);
-  for (int t = 0; t < ntiles; ++t) {
+  if (t_begin < ntiles) prefetch(t_begin);
+  for (int t = t_begin; t < ntiles; ++t) {
     __syncthreads();
     commit();
     __syncthreads();
     if (t + 1 < ntiles) prefetch(t + 1);
+    if (!wave_active) continue;
 
     // ---- S^T tile: 4 sub-tiles of 16 keys
     f32x4_t st[4];
@@ -194,6 +209,17 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
   // ---- finalise: l is a per-lane partial over this lane's key slots
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
+  if (SPLIT) {
+    if (qi < p.Sq) {
+      const long long slot = ((static_cast<long long>(b) * p.Hq + h) * p.nsplit + blockIdx.x) * p.Sq + qi;
+      float* po = p.part_o + slot * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        *reinterpret_cast<f32x4_t*>(po + dt * 16 + g * 4) = o[dt];
+      if (g == 0) { p.part_ml[slot * 2] = m; p.part_ml[slot * 2 + 1] = l; }
+    }
+    return;
+  }
   const float inv = l > 0.f ? 1.f / l : 0.f;
   if (qi < p.Sq) {
     bf16_t* op = p.o + b * p.o_sb + static_cast<long long>(qi) * p.o_ss + h * p.o_sh;
@@ -206,11 +232,35 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
   }
 }
 
+// Merge the key splits of one query row: thread d owns output column d.
+template <int D>
+__global__ __launch_bounds__(D) void attn_split_combine_kernel(AttnParams p) {
+  const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
+  const long long base = (static_cast<long long>(b) * p.Hq + h) * p.nsplit;
+  float mx = -INFINITY;
+  for (int s = 0; s < p.nsplit; ++s) mx = fmaxf(mx, p.part_ml[((base + s) * p.Sq + qi) * 2]);
+  float acc = 0.f, l = 0.f;
+  if (mx != -INFINITY) {
+    for (int s = 0; s < p.nsplit; ++s) {
+      const long long slot = (base + s) * p.Sq + qi;
+      const float ms = p.part_ml[slot * 2];
+      if (ms == -INFINITY) continue;
+      const float w = exp2f(ms - mx);
+      l += w * p.part_ml[slot * 2 + 1];
+      acc += w * p.part_o[slot * D + d];
+    }
+  }
+  bf16_t* op = p.o + b * p.o_sb + static_cast<long long>(qi) * p.o_ss + h * p.o_sh;
+  op[d] = f32_to_bf16(l > 0.f ? acc / l : 0.f);
+}
+
 void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o,
                          const long long* strides /*12: q,k,v,o x (b,s,h)*/, const int* kv_len,
                          int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, int q_offset,
-                         int q_offset_from_len, float scale, hipStream_t st) {
+                         int q_offset_from_len, float scale, hipStream_t st, float* part_o,
+                         float* part_ml, int nsplit) {
   AttnParams p;
+  p.part_o = part_o; p.part_ml = part_ml; p.nsplit = nsplit;
   p.q = q; p.k = k; p.v = v; p.o = o;
   p.q_sb = strides[0]; p.q_ss = strides[1]; p.q_sh = strides[2];
   p.k_sb = strides[3]; p.k_ss = strides[4]; p.k_sh = strides[5];
@@ -219,6 +269,18 @@ void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16
   p.kv_len = kv_len; p.Sq = Sq; p.Sk = Sk; p.Hq = Hq; p.Hkv = Hkv;
   p.q_offset = q_offset; p.q_offset_from_len = q_offset_from_len;
   p.scale_log2e = scale * 1.4426950408889634f;
+  if (nsplit > 0) {
+    // few query rows (Sq <= 64), causal, long cache: split the keys over blocks
+    dim3 sgrid(nsplit, Hq, B), cgrid(Sq, Hq, B);
+    if (D == 128) {
+      hipLaunchKernelGGL((attn_prefill_kernel<128, true, true>), sgrid, dim3(256), 0, st, p);
+      hipLaunchKernelGGL((attn_split_combine_kernel<128>), cgrid, dim3(128), 0, st, p);
+    } else {
+      hipLaunchKernelGGL((attn_prefill_kernel<64, true, true>), sgrid, dim3(256), 0, st, p);
+      hipLaunchKernelGGL((attn_split_combine_kernel<64>), cgrid, dim3(64), 0, st, p);
+    }
+    return;
+  }
   dim3 grid((Sq + 63) / 64, Hq, B), block(256);
   if (D == 128) {
     if (causal) hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, block, 0, st, p);

@@ -121,10 +121,15 @@ __global__ __launch_bounds__(256) void rope_kv_prefill_kernel(
     const int s = static_cast<int>(i / per_tok);
     const int rem = static_cast<int>(i % per_tok);
     const int h = rem / cph, c = rem % cph;
-    const int pos = (pos0 ? pos0[b] : 0) + s;
+    int pos = (pos0 ? pos0[b] : 0) + s;
+    // positions come from a device counter: a row that would land outside the
+    // cache is dropped (its q row still gets a finite value from the last slot)
+    const bool in_cache = pos >= 0 && pos < l_max;
+    pos = pos < 0 ? 0 : (pos >= l_max ? l_max - 1 : pos);
     const bf16_t* src = qkv + (static_cast<size_t>(b) * S + s) * heads * D + h * D + c * 8;
     u32x4_t a = load16(src), bb = load16(src + hh);
     bf16_t* dst;
+    if (h >= Hq && !in_cache) continue;
     if (h < Hq) {
       dst = q_out + (static_cast<size_t>(b) * S + s) * Hq * D + h * D;
     } else if (h < Hq + Hkv) {

@@ -252,7 +252,11 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
         } else if constexpr (E == E_QKV_ROPE) {
           const int hd = p.head_dim, hh = hd >> 1;
           const int q_rows = p.n_q_heads * hd, k_rows = p.n_kv_heads * hd;
-          const int pos = p.pos[b];
+          // the position is a device counter: clamp it into the cache so a
+          // sequence that ran past its capacity overwrites the last slot
+          // instead of writing outside the allocation
+          const int pos_raw = p.pos[b];
+          const int pos = pos_raw < 0 ? 0 : (pos_raw >= p.l_max ? p.l_max - 1 : pos_raw);
           if (row[0] < q_rows + k_rows) {
             const int h_all = row[0] / hd, j = row[0] % hd;  // j < hh
             bf16_t* dst;

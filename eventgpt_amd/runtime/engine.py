@@ -113,8 +113,10 @@ class GenerationEngine:
         self.sampled = torch.zeros(B, **i32)
         self.sd_result = torch.zeros(4, **i32)  # [n_accepted, next_token, n_emitted, -]
         self.eos = int(cfg.eos_token_id if cfg.eos_token_id is not None else -1)
-        self._graph_greedy = None
+        # captured graphs bake the EOS id (a launch argument), so they are keyed by it
+        self._graph_greedy = {}
         self._graph_logits = None
+        self._verify_graphs = {}
 
     # ---------------------------------------------------------------- weights
     def _setup_parallel(self) -> None:
@@ -228,17 +230,41 @@ class GenerationEngine:
         the device.  Returns the G+1 hidden rows (post final-norm) if asked — the
         verifier-side states that B1 / L5F adapters consume.
         """
-        raw = self.raw
         G = int(draft.shape[0]) if n_draft is None else int(n_draft)
-        toks = torch.cat([self.cur_token[:1], draft[:G].to(torch.int32)]).long()
+        if G < 1 or G > 63:
+            raise ValueError(f"verify takes 1..63 draft tokens, got {G}")
+        draft = draft[:G].to(torch.int32)
+        if not self.use_graph:
+            hn = self._verify_body(draft.contiguous(), G)
+            return hn if return_hidden else None
+        # one captured graph per draft length: the whole verify (embed gather, layers,
+        # lm_head argmax, accept kernel) replays as a single launch; positions, the
+        # current token and the EOS id are all read from device memory
+        entry = self._verify_graphs.get((G, self.eos))
+        if entry is None:
+            static_draft = torch.zeros(G, dtype=torch.int32, device=self.device)
+            static_draft.copy_(draft)
+            box = {}
+            keep = [t.clone() for t in (self.out_tokens, self.sd_result)]
+            g = self._capture(lambda: box.__setitem__("hn", self._verify_body(static_draft, G)))
+            self.out_tokens.copy_(keep[0]); self.sd_result.copy_(keep[1])
+            entry = (g, static_draft, box["hn"])
+            self._verify_graphs[(G, self.eos)] = entry
+        g, static_draft, hn = entry
+        static_draft.copy_(draft)
+        g.replay()
+        return hn.clone() if return_hidden else None
+
+    def _verify_body(self, draft: torch.Tensor, G: int) -> torch.Tensor:
+        raw = self.raw
+        toks = torch.cat([self.cur_token[:1], draft]).long()
         emb = self.embed.index_select(0, toks.clamp_(0, self.embed.shape[0] - 1))
         h = self._forward_rows(emb, 0, self.pos[:1])
         hn = raw.rmsnorm(h, self.final_norm, self.eps)
         pv, pi = raw.linear_argmax_partials(hn.view(G + 1, self.H), self.lm_head, None)
-        raw.verify_accept(pv, pi, draft.to(torch.int32).contiguous(), G, self.out_tokens, self.step,
-                          self.pos, self.done, self.cur_token, self.sd_result, self.eos,
-                          self.embed, self.x)
-        return hn.view(G + 1, self.H) if return_hidden else None
+        raw.verify_accept(pv, pi, draft, G, self.out_tokens, self.step, self.pos, self.done,
+                          self.cur_token, self.sd_result, self.eos, self.embed, self.x)
+        return hn.view(G + 1, self.H)
 
     # ------------------------------------------------------------ decode step
     def _layers_step(self) -> None:
@@ -299,9 +325,10 @@ class GenerationEngine:
             (self._step_greedy if greedy else self._step_logits)()
             return
         if greedy:
-            if self._graph_greedy is None:
-                self._graph_greedy = self._capture(self._step_greedy)
-            self._graph_greedy.replay()
+            g = self._graph_greedy.get(self.eos)
+            if g is None:
+                g = self._graph_greedy[self.eos] = self._capture(self._step_greedy)
+            g.replay()
         else:
             if self._graph_logits is None:
                 self._graph_logits = self._capture(self._step_logits)

@@ -98,19 +98,22 @@ class DualModelScheduler:
 
     # ----------------------------------------------------------- prefill hiding
     @torch.no_grad()
-    def prefill_hiding(self, d_embeds, v_embeds, max_new_tokens: int = 50, max_free: int = 30,
-                       eos_token_id: int = 2, token_map: Optional[Callable] = None) -> Dict:
-        """Drafter prefill + free-running decode in parallel with the verifier's prefill,
-        then one batched verify of the free tokens and autoregressive continuation.
+    def hidden_prefill(self, d_embeds, v_embeds, max_free: int = 30, eos_token_id: int = 2,
+                       token_map: Optional[Callable] = None, want_verifier_hidden: bool = False) -> Dict:
+        """Drafter prefill + free-running decode in parallel with the verifier's prefill.
 
-        Draft tokens come from ``draft_head`` applied to the drafter's hidden states
-        when one is configured, else from the drafter's own tokens (optionally
-        translated by ``token_map`` when the vocabularies differ).
+        Returns the draft tokens produced inside the window (from ``draft_head``
+        applied to the drafter's hidden states when one is configured, else the
+        drafter's own tokens, optionally translated by ``token_map`` when the
+        vocabularies differ), the timings, and — on request — the verifier hidden
+        row that predicts its second token.  The verifier is left prefilled with
+        its first token committed.
         """
         stop = threading.Event()
         d, v = self.d, self.v
         d.eos, v.eos = eos_token_id, eos_token_id
         hidden_rows = []
+        v_hidden = []
 
         def run_drafter():
             with self.d_lock, torch.cuda.device(d.device), torch.cuda.stream(self.d_stream):
@@ -140,7 +143,15 @@ class DualModelScheduler:
 
         def run_verifier():
             try:
-                return self._timed_prefill(v, self.v_stream, v_embeds, self.v_lock)
+                with self.v_lock, torch.cuda.device(v.device), torch.cuda.stream(self.v_stream):
+                    self.v_stream.synchronize()
+                    t0 = time.perf_counter()
+                    v.reset()
+                    h = v.prefill(v_embeds, select="greedy", return_hidden=want_verifier_hidden)
+                    if want_verifier_hidden:
+                        v_hidden.append(ops.rmsnorm(h[-1:], v.final_norm, v.eps))
+                    self.v_stream.synchronize()
+                    return (time.perf_counter() - t0) * 1e3
             finally:
                 stop.set()
 
@@ -152,19 +163,28 @@ class DualModelScheduler:
         n_free = d_info["n_free"]
         with torch.cuda.device(v.device):
             if self.head is not None:
-                hid = torch.cat(hidden_rows)[:n_free].to(v.device)
-                draft = self.head(hid)
+                draft = self.head(torch.cat(hidden_rows)[:n_free].to(v.device))
             else:
                 draft = _emitted(d)[:n_free].to(v.device)
                 if token_map is not None:
                     draft = token_map(draft)
-            sd = SpecDecodeEngine(v, self.head)
-            toks, stats = sd.verify_free_tokens(draft.to(torch.int32), max_new_tokens, eos_token_id,
-                                                drop_first=True)
-        return {"tokens": toks, "stats": stats.as_dict(), "n_free": n_free,
-                "egpt_prefill_ms": d_info["prefill_ms"], "vl_prefill_ms": v_ms,
-                "prefill_wall_ms": wall_prefill, "decode_ms": stats.decode_ms,
-                "total_ms": wall_prefill + stats.decode_ms}
+        return {"draft": draft.to(torch.int32), "n_free": n_free, "egpt_prefill_ms": d_info["prefill_ms"],
+                "egpt_total_ms": d_info["total_ms"], "vl_prefill_ms": v_ms, "prefill_wall_ms": wall_prefill,
+                "verifier_hidden": v_hidden[0] if v_hidden else None}
+
+    @torch.no_grad()
+    def prefill_hiding(self, d_embeds, v_embeds, max_new_tokens: int = 50, max_free: int = 30,
+                       eos_token_id: int = 2, token_map: Optional[Callable] = None) -> Dict:
+        """``hidden_prefill`` + one batched verify of the free tokens + autoregressive
+        continuation on the verifier."""
+        pre = self.hidden_prefill(d_embeds, v_embeds, max_free, eos_token_id, token_map)
+        with torch.cuda.device(self.v.device):
+            sd = SpecDecodeEngine(self.v, self.head)
+            toks, stats = sd.verify_free_tokens(pre["draft"], max_new_tokens, eos_token_id, drop_first=True)
+        return {"tokens": toks, "stats": stats.as_dict(), "n_free": pre["n_free"],
+                "egpt_prefill_ms": pre["egpt_prefill_ms"], "vl_prefill_ms": pre["vl_prefill_ms"],
+                "prefill_wall_ms": pre["prefill_wall_ms"], "decode_ms": stats.decode_ms,
+                "total_ms": pre["prefill_wall_ms"] + stats.decode_ms}
 
     # ----------------------------------------------------------------- baseline
     @torch.no_grad()

@@ -208,13 +208,18 @@ class SpecDecodeEngine:
 
     @torch.no_grad()
     def verify_free_tokens(self, draft_tokens: torch.Tensor, max_new_tokens: int = 50,
-                           eos_token_id: int = 2, drop_first: bool = True) -> tuple:
+                           eos_token_id: int = 2, drop_first: bool = True,
+                           continue_ar: bool = True, want_hidden: bool = False) -> tuple:
         """Prefill hiding: the drafter produced ``draft_tokens`` while the verifier was
         prefilling.  They are checked in ONE batched verify, then the verifier
         continues autoregressively.  ``drop_first``: the first draft token
         duplicates the verifier's own first token and is skipped
-        (benchmark_e2e_wallclock.py:1766-1773)."""
+        (benchmark_e2e_wallclock.py:1766-1773).  With ``continue_ar=False`` only the
+        batched verify runs (a decode-phase drafter takes over afterwards);
+        ``want_hidden`` keeps the verifier hidden row that predicts the next token
+        in ``self.next_hidden`` for the gamma=1 feedback modes."""
         v = self.v
+        self.next_hidden = None
         v.eos = eos_token_id
         stats = SDStats()
         torch.cuda.synchronize()
@@ -222,8 +227,10 @@ class SpecDecodeEngine:
         d = draft_tokens[1:] if drop_first else draft_tokens
         d = d[: min(d.shape[0], 63, max_new_tokens - 1)]
         if d.shape[0] > 0:
-            self._verify(d.to(torch.int32), stats, False)
-        while int(v.step[0].item()) < max_new_tokens and not int(v.done[0].item()):
+            n_acc, vh = self._verify(d.to(torch.int32), stats, want_hidden)
+            if want_hidden:
+                self.next_hidden = vh[n_acc:n_acc + 1].clone()
+        while continue_ar and int(v.step[0].item()) < max_new_tokens and not int(v.done[0].item()):
             remaining = max_new_tokens - int(v.step[0].item())
             for _ in range(min(v.poll_every, remaining)):
                 v.decode_step(True)

@@ -144,3 +144,24 @@ def test_argmax(dev):
     xb = x.to(torch.bfloat16)
     got = _hip().argmax_last(xb)
     assert torch.equal(xb.float().gather(1, got[:, None]), xb.float().max(-1, keepdim=True).values)
+
+
+@pytest.mark.parametrize("D,Hq,Hkv,Sq,kv,Lmax", [(128, 8, 8, 6, 1000, 1536), (128, 4, 2, 1, 77, 512),
+                                                  (64, 4, 4, 17, 300, 640), (128, 4, 4, 64, 64, 512),
+                                                  (128, 4, 4, 100, 700, 1024), (128, 2, 2, 3, 5, 256)])
+def test_attention_against_cache(dev, D, Hq, Hkv, Sq, kv, Lmax):
+    """Queries at the tail of a static cache (split-KV path for <= 64 rows on a long
+    cache, block-per-64-rows path otherwise) against the fp32 reference."""
+    from eventgpt_amd.ops import hip, reference
+    g = torch.Generator(device=dev).manual_seed(D + Sq + kv)
+    q = torch.randn(1, Sq, Hq, D, device=dev, generator=g).to(torch.bfloat16)
+    kc = torch.randn(1, Hkv, Lmax, D, device=dev, generator=g).to(torch.bfloat16)
+    vc = torch.randn(1, Hkv, Lmax, D, device=dev, generator=g).to(torch.bfloat16)
+    out = torch.empty_like(q)
+    kv_len = torch.tensor([kv], dtype=torch.int32, device=dev)
+    hip.raw.attention_cache(q, kc, vc, out, kv_len, D ** -0.5)
+    rep = Hq // Hkv
+    k = kc[:, :, :kv].transpose(1, 2).float().repeat_interleave(rep, dim=2)
+    v = vc[:, :, :kv].transpose(1, 2).float().repeat_interleave(rep, dim=2)
+    ref = reference.attention(q.float(), k, v, causal=True, q_offset=kv - Sq)
+    assert torch.allclose(out.float(), ref, atol=2e-2, rtol=2e-2), (out.float() - ref).abs().max()

@@ -63,6 +63,36 @@ def test_verify_accept_kernel_cases(target, dev):
     assert int(eng.done[0]) == 1 and int(eng.step[0]) == k + 1
 
 
+def test_verify_graph_replays_match_eager(target, dev):
+    """The captured verify is replayed with other eager work and syncs in between;
+    every replay must equal the eager (uncaptured) verify from the same state."""
+    from eventgpt_amd.runtime.engine import GenerationEngine
+    emb = _emb(dev, 37, seed=9)
+    eager = GenerationEngine(target, max_len=512, max_new_tokens=128, use_graph=False)
+    graph = GenerationEngine(target, max_len=512, max_new_tokens=128, use_graph=True)
+    greedy = graph.generate(emb, 40, eos_token_id=-1)
+    for e in (eager, graph):
+        e.eos = -1
+        e.reset()
+        e.prefill(emb, select="greedy")
+    g = torch.Generator(device=dev).manual_seed(1)
+    for it in range(7):
+        n = int(graph.step[0].item())
+        draft = greedy[n:n + 4].to(torch.int32).clone()
+        if it % 2:                                  # corrupt one position on odd rounds
+            k = int(torch.randint(0, 4, (1,), device=dev, generator=g))
+            draft[k] = (draft[k] + 1) % 128
+        he = eager.verify(draft, 4, return_hidden=True)
+        hg = graph.verify(draft, 4, return_hidden=True)
+        _ = (torch.randn(256, 256, device=dev) @ torch.randn(256, 256, device=dev)).sum().item()
+        assert torch.equal(eager.sd_result[:3], graph.sd_result[:3]), it
+        assert torch.equal(eager.pos, graph.pos) and torch.equal(eager.step, graph.step)
+        assert torch.allclose(he.float(), hg.float(), atol=2e-2, rtol=2e-2)
+    n = int(graph.step[0].item())
+    assert torch.equal(graph.out_tokens[0, :n].long(), greedy[:n])
+    assert torch.equal(eager.out_tokens[0, :n].long(), greedy[:n])
+
+
 def test_naive_sd_is_lossless(target, drafter, dev):
     from eventgpt_amd.runtime.spec_decode import NaiveSpeculativeDecoder
     emb = _emb(dev, 33, seed=3)
