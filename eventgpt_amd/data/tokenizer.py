@@ -81,6 +81,14 @@ class ByteTokenizer:
     def convert_tokens_to_ids(self, token: str) -> int:
         return self.added.get(token, self.unk_token_id)
 
+    def get_vocab(self) -> Dict[str, int]:
+        """Specials, the 256 byte tokens (``<0xNN>`` like sentencepiece byte fallback)
+        and the added tokens; unused filler ids have no string."""
+        v = {"<unk>": self.unk_token_id, "<s>": self.bos_token_id, "</s>": self.eos_token_id}
+        v.update({f"<0x{b:02X}>": b + self._BYTE_BASE for b in range(256)})
+        v.update(self.added)
+        return v
+
     # -- encode / decode ----------------------------------------------------
     def encode(self, text: str, add_special_tokens: bool = True) -> List[int]:
         ids: List[int] = [self.bos_token_id] if (self.add_bos and add_special_tokens) else []
