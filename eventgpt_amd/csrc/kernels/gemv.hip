@@ -22,6 +22,8 @@
 //     pairs j, j+D/2), fp32 logits + per-block argmax partials.
 // Positions / cache lengths are read from device memory so a captured graph can
 // be replayed for every token.
+#include <cstdlib>
+
 #include "common.h"
 #include "../evgpt_kernels.h"
 
@@ -55,6 +57,9 @@ struct GemvParams {
   int* part_idx;
 };
 
+#ifndef EVGPT_GEMV_PRE
+#define EVGPT_GEMV_PRE 1       // weight chunk-iterations requested ahead of the fused norm
+#endif
 constexpr int R = 4;           // rows per unit
 constexpr int GEMV_WAVES = 4;  // waves per block
 
@@ -96,45 +101,105 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
   const int ks = wid % KS, ub_slot = wid / KS;
   const int nchunk = p.K >> 3;
 
+  // this wave's slice of the K range, in 16-byte chunks
+  const int cper = (nchunk + KS - 1) / KS;
+  const int c_begin = ks * cper;
+  const int c_end = min(c_begin + cper, nchunk);
+  const int n_units = (p.N + R - 1) / R;
+  const int n_ub = (n_units + UPB - 1) / UPB;
+
   // ---------------- prologue: normalise x into LDS (fused RMSNorm) ----------------
+  // The weights do not depend on x, so the first PRE chunk-iterations of this
+  // wave's first unit are requested before the norm: the HBM round trip of the
+  // first weight bytes then overlaps the reduction instead of following it.
+  constexpr int PRE = EVGPT_GEMV_PRE;
+  u32x4_t pre[PRE > 0 ? PRE : 1][R];
   if constexpr (P == P_RMSNORM) {
+    {
+      const int u = blockIdx.x * UPB + ub_slot;
+      int row[R];
+      unit_rows<E>(p, u < n_units ? u : n_units - 1, row);
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      float ss = 0.f;
-      for (int c = tid; c < nchunk; c += blockDim.x) {
-        u32x4_t v = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+      for (int i = 0; i < PRE; ++i) {
+        const int c = c_begin + lane + 64 * i;
+        const int cc = c < c_end ? c : 0;  // out-of-slice lanes load a valid address and drop it
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float lo = bf16lo(v[i]), hi = bf16hi(v[i]);
-          ss += lo * lo + hi * hi;
+        for (int r = 0; r < R; ++r) {
+          const int rr = row[r] < p.N ? row[r] : p.N - 1;
+          pre[i][r] = load_stream16(p.W + static_cast<size_t>(rr) * p.K + cc * 8);
         }
       }
-      ss = block_sum(ss, red);
-      const float rstd = rsqrtf(ss / static_cast<float>(p.K) + p.eps);
-      for (int c = tid; c < nchunk; c += blockDim.x) {
-        u32x4_t v = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
-        u32x4_t w = load16(p.norm_w + c * 8);
-        u32x4_t o;
+    }
+    constexpr int XC = 2;  // x chunks a thread keeps in registers between the two passes
+    if (nchunk <= XC * GEMV_WAVES * 64) {
+      u32x4_t nw[XC];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          // HF order: round x*rstd to bf16, then multiply by the bf16 weight
-          const float lo = bf16_to_f32(f32_to_bf16(bf16lo(v[i]) * rstd)) * bf16lo(w[i]);
-          const float hi = bf16_to_f32(f32_to_bf16(bf16hi(v[i]) * rstd)) * bf16hi(w[i]);
-          o[i] = pack_bf16x2(lo, hi);
+      for (int i = 0; i < XC; ++i) {
+        const int c = tid + i * GEMV_WAVES * 64;
+        nw[i] = c < nchunk ? load16(p.norm_w + c * 8) : u32x4_t{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        u32x4_t xv[XC];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < XC; ++i) {
+          const int c = tid + i * GEMV_WAVES * 64;
+          xv[i] = c < nchunk ? load16(p.x + (static_cast<size_t>(b) * p.K + c * 8))
+                             : u32x4_t{0, 0, 0, 0};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float lo = bf16lo(xv[i][j]), hi = bf16hi(xv[i][j]);
+            ss += lo * lo + hi * hi;
+          }
         }
-        xs[b * nchunk + c] = o;
+        ss = block_sum(ss, red);
+        const float rstd = rsqrtf(ss / static_cast<float>(p.K) + p.eps);
+#pragma unroll
+        for (int i = 0; i < XC; ++i) {
+          const int c = tid + i * GEMV_WAVES * 64;
+          u32x4_t o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            // HF order: round x*rstd to bf16, then multiply by the bf16 weight
+            const float lo = bf16_to_f32(f32_to_bf16(bf16lo(xv[i][j]) * rstd)) * bf16lo(nw[i][j]);
+            const float hi = bf16_to_f32(f32_to_bf16(bf16hi(xv[i][j]) * rstd)) * bf16hi(nw[i][j]);
+            o[j] = pack_bf16x2(lo, hi);
+          }
+          if (c < nchunk) xs[b * nchunk + c] = o;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        float ss = 0.f;
+        for (int c = tid; c < nchunk; c += blockDim.x) {
+          u32x4_t v = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float lo = bf16lo(v[i]), hi = bf16hi(v[i]);
+            ss += lo * lo + hi * hi;
+          }
+        }
+        ss = block_sum(ss, red);
+        const float rstd = rsqrtf(ss / static_cast<float>(p.K) + p.eps);
+        for (int c = tid; c < nchunk; c += blockDim.x) {
+          u32x4_t v = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+          u32x4_t w = load16(p.norm_w + c * 8);
+          u32x4_t o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float lo = bf16_to_f32(f32_to_bf16(bf16lo(v[i]) * rstd)) * bf16lo(w[i]);
+            const float hi = bf16_to_f32(f32_to_bf16(bf16hi(v[i]) * rstd)) * bf16hi(w[i]);
+            o[i] = pack_bf16x2(lo, hi);
+          }
+          xs[b * nchunk + c] = o;
+        }
       }
     }
     __syncthreads();
   }
 
-  // this wave's slice of the K range, in 16-byte chunks
-  const int cper = (nchunk + KS - 1) / KS;
-  const int c_begin = ks * cper;
-  const int c_end = min(c_begin + cper, nchunk);
-
-  const int n_units = (p.N + R - 1) / R;
-  const int n_ub = (n_units + UPB - 1) / UPB;
   float best_val[B];
   int best_idx[B];
   if constexpr (E == E_LOGITS) {
@@ -160,11 +225,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
 #pragma unroll
       for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
 
-#pragma unroll 4
-    for (int c = c_begin + lane; c < c_end; c += 64) {
-      u32x4_t wv[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) wv[r] = load_stream16(wp[r] + c * 8);
+    auto consume = [&](const u32x4_t (&wv)[R], int c) {
 #pragma unroll
       for (int b = 0; b < B; ++b) {
         u32x4_t xv;
@@ -173,6 +234,23 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r][b] = dot8_bf16(wv[r], xv, acc[r][b]);
       }
+    };
+    int c = c_begin + lane;
+    if constexpr (P == P_RMSNORM) {
+      if (ub == blockIdx.x) {  // the chunks requested ahead of the norm
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+          if (c < c_end) consume(pre[i], c);
+          c += 64;
+        }
+      }
+    }
+#pragma unroll 4
+    for (; c < c_end; c += 64) {
+      u32x4_t wv[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) wv[r] = load_stream16(wp[r] + c * 8);
+      consume(wv, c);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -321,8 +399,16 @@ static int pick_ks(int N) {
 static int gemv_grid(int N, int ks) {
   const int units = (N + R - 1) / R;
   const int upb = GEMV_WAVES / ks;
-  int blocks = (units + upb - 1) / upb;
-  const int cap = 256 * 8;  // 8 blocks per CU; the rest is a grid-stride loop
+  const int blocks = (units + upb - 1) / upb;
+  // 8 blocks per CU are resident.  Measured on MI355X (7B decode step): letting
+  // the dispatcher hand out up to 4096 one-unit blocks beats a 2048-block grid
+  // whose blocks loop (2.79 vs 2.82 ms per token), and an even split of units
+  // over fewer blocks is slower than both.  EVGPT_GEMV_CAP overrides for tuning.
+  static const int cap = [] {
+    const char* e = getenv("EVGPT_GEMV_CAP");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 4096;
+  }();
   return blocks < cap ? blocks : cap;
 }
 
