@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--parallelism", choices=["dp", "tp"], default="dp")
     ap.add_argument("--model", choices=["7b", "small"], default="7b")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--nsplit", type=int, default=None, help="KV splits of the decode attention")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,14 +77,15 @@ def main():
     torch.manual_seed(1234 + rank)
     model = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=1234)
 
+    ekw = {} if args.nsplit is None else {"nsplit": args.nsplit}
     if args.parallelism == "tp" and world > 1:
         from eventgpt_amd.parallel.tp import TensorParallelEngine
         engine = TensorParallelEngine(model, dist.group.WORLD, max_len=2048,
                                       max_new_tokens=args.steps + args.warmup + 8,
-                                      use_graph=not args.no_graph)
+                                      use_graph=not args.no_graph, **ekw)
     else:
         engine = model.engine(max_len=2048, max_new_tokens=args.steps + args.warmup + 8,
-                              use_graph=not args.no_graph)
+                              use_graph=not args.no_graph, **ekw)
 
     def sync_all():
         if dist is not None:

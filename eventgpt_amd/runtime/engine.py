@@ -52,7 +52,7 @@ def _pad_rows(w: torch.Tensor, mult: int) -> torch.Tensor:
 
 
 class GenerationEngine:
-    def __init__(self, model, max_len: int = 2560, max_batch: int = 1, nsplit: int = 8,
+    def __init__(self, model, max_len: int = 2560, max_batch: int = 1, nsplit: int = 16,
                  use_graph: bool = True, max_new_tokens: int = 1024, poll_every: int = 16):
         from ..ops import hip  # raises if the extension is missing
         self.raw = hip.raw

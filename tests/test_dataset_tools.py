@@ -120,3 +120,37 @@ def test_alignment_feature_builder(tmp_path):
     assert DT.build_alignment_features(model, proc, ds, str(tmp_path / "feat"))["skipped"] == 2
     ans = DT.model_answerer(model, proc, ds, max_new_tokens=3)(ds[0], "What?")
     assert isinstance(ans[0], str) and 0.0 < ans[1] <= 1.0
+
+
+def test_snapshot_io_and_validation(tmp_path):
+    import json as _json
+    import os as _os
+
+    import numpy as _np
+
+    from eventgpt_amd.pipeline import dataset_io as DIO
+    from eventgpt_amd.pipeline.dataset import JSON_NAME, make_synthetic_dataset
+    root = make_synthetic_dataset(str(tmp_path / "ds"), n_samples=4, n_events=500, width=32, height=24)
+    entries = DIO.load_snapshot(root)
+    assert len(entries) == 4 and DIO.find_snapshot_json(root).endswith(JSON_NAME)
+    rep = DIO.validate_dataset(root, n_event_checks=-1, out=lambda *_: None)
+    assert rep["n_valid"] == 4 and not rep["issues"] and len(rep["event_stats"]) == 4
+    assert rep["event_stats"][0]["num_events"] == 500 and rep["event_stats"][0]["width"] <= 32
+    # break three entries in three different ways
+    entries[0]["conversations"][0]["from"] = "gpt"
+    entries[1].pop("event_data")
+    _os.remove(_os.path.join(root, "event_npy", entries[2]["event_data"]))
+    with open(_os.path.join(root, JSON_NAME), "w") as f:
+        _json.dump(entries, f)
+    # and make the fourth event file something the array-only loader must refuse
+    class Evil:
+        def __reduce__(self):
+            return (print, ("executed",))
+    _np.save(_os.path.join(root, "event_npy", entries[3]["event_data"]), _np.array({"x": Evil()}, dtype=object),
+             allow_pickle=True)
+    rep = DIO.validate_dataset(root, n_event_checks=-1, out=lambda *_: None)
+    assert rep["n_valid"] == 0 and len(rep["issues"]) == 4
+    kinds = " | ".join(i["issue"] for i in rep["issues"])
+    assert "human -> gpt" in kinds and "missing fields" in kinds and "not found" in kinds and "event data" in kinds
+    ds = DIO.load_snapshot(root, as_hf=True)
+    assert len(ds) == 4 and "conversations" in ds.column_names
