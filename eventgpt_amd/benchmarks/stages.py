@@ -32,6 +32,7 @@ from ..data.tokenizer import tokenizer_event_token
 from ..eval.reports import markdown_table, write_json
 from ..eval.timers import StageTimer, estimate_kv_cache_mb, gpu_memory_mb
 from ..models.video_llava import VIDEO_PROMPT, load_video_frames
+from ..ops.event_ops import preprocess_frames
 from ..pipeline.dataset import DEFAULT_QUESTION, InstructionDataset
 
 STAGE_KEYS = ("stage1_time", "stage2_time", "stage3_time", "stage4_time", "stage5_time")
@@ -135,8 +136,7 @@ class EventGPTStages:
                 raw = [np.asarray(load_image(p)) for p in paths]
         with timer.stage("stage2_time", host=True):
             imgs = event_frames(raw, self.num_frames) if self.source == "npy" else raw
-            proc = m.get_visual_tower().event_processor
-            px = [proc(im, return_tensors="pt")["pixel_values"][0].to(m.device, m.dtype) for im in imgs]
+            px = list(preprocess_frames(imgs, m.device, m.get_visual_tower().event_processor.size, m.dtype))
             ids = tokenizer_event_token(prepare_event_prompt(query, "eventgpt_v1"), self.tok, EVENT_TOKEN_INDEX,
                                         return_tensors="pt")[None].to(m.device)
         with timer.stage("stage3_time"), torch.no_grad():
@@ -163,9 +163,9 @@ class VideoLlavaStages:
             if not frames:
                 return None
         with timer.stage("stage2_time", host=True):
-            inp = self.proc(VIDEO_PROMPT.format(query=query), frames)
+            inp = self.proc(VIDEO_PROMPT.format(query=query), frames, device=m.device, dtype=m.dtype)
             ids = inp["input_ids"].to(m.device)
-            px = inp["pixel_values_videos"].to(m.device, m.dtype)
+            px = inp["pixel_values_videos"]
         with timer.stage("stage3_time"), torch.no_grad():
             feats = m.get_video_features(px)
             emb = m.merge_video_features(ids, feats)[0]

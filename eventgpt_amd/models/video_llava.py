@@ -377,7 +377,12 @@ class VideoProcessor:
         self.tokenizer = tokenizer
         self.image_processor = EventImageProcessor(config.vision_config.image_size)
 
-    def frames(self, frames: Sequence[np.ndarray]) -> torch.Tensor:
+    def frames(self, frames: Sequence[np.ndarray], device=None, dtype=torch.bfloat16) -> torch.Tensor:
+        """``device`` given: preprocess there (one HIP kernel on a GPU) and return ``dtype``;
+        otherwise fp32 on the host, like an HF processor."""
+        if device is not None:
+            from ..ops.event_ops import preprocess_frames
+            return preprocess_frames(frames, device, self.config.vision_config.image_size, dtype)[None]
         px = [self.image_processor(np.asarray(f), return_tensors="pt")["pixel_values"][0] for f in frames]
         return torch.stack(px)[None]
 
@@ -392,10 +397,11 @@ class VideoProcessor:
             b = b[1:]
         return torch.tensor([a + [self.config.video_token_index] + b], dtype=torch.long)
 
-    def __call__(self, text: str, videos: Sequence[np.ndarray], return_tensors: str = "pt") -> dict:
+    def __call__(self, text: str, videos: Sequence[np.ndarray], return_tensors: str = "pt", device=None,
+                 dtype=torch.bfloat16) -> dict:
         ids = self.prompt_ids(text) if "<video>" not in text else self._raw(text)
         return {"input_ids": ids, "attention_mask": torch.ones_like(ids),
-                "pixel_values_videos": self.frames(videos)}
+                "pixel_values_videos": self.frames(videos, device, dtype)}
 
     def _raw(self, text: str) -> torch.Tensor:
         head, tail = text.split("<video>")

@@ -312,12 +312,28 @@ class GenerationEngine:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread-local capture mode: another host thread driving a second engine on
+        # its own stream must not invalidate this capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             fn()
         for t, s in zip((self.step, self.pos, self.done, self.cur_token, self.x), saved):
             t.copy_(s)
         torch.cuda.synchronize()
         return g
+
+    def ensure_graphs(self, eos_token_id: Optional[int] = None, greedy: bool = True) -> None:
+        """Capture the decode graph for this EOS id now, if it is not captured yet.
+        Schedulers call this before they start timed or multi-threaded regions, so
+        that no capture (which synchronises the device) lands inside them."""
+        if eos_token_id is not None:
+            self.eos = int(eos_token_id)
+        if not self.use_graph:
+            return
+        if greedy:
+            if self.eos not in self._graph_greedy:
+                self._graph_greedy[self.eos] = self._capture(self._step_greedy)
+        elif self._graph_logits is None:
+            self._graph_logits = self._capture(self._step_logits)
 
     def decode_step(self, greedy: bool = True) -> None:
         """Advance every sequence by one token (graph replay when enabled)."""

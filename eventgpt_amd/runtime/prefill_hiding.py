@@ -120,6 +120,9 @@ class PrefillOnlyInference:
     @torch.no_grad()
     def generate(self, d_embeds, v_embeds, eos_token_id: int = 2) -> PrefillOnlyResult:
         s = self.sched
+        for eng in (s.d, s.v):
+            with torch.cuda.device(eng.device):
+                eng.ensure_graphs(eos_token_id)
         s._sync_all()
         t0 = time.perf_counter()
         d, v = _run_threads([lambda: self._generate(s.d, s.d_stream, s.d_lock, d_embeds, eos_token_id),

@@ -111,7 +111,9 @@ class DualModelScheduler:
         """
         stop = threading.Event()
         d, v = self.d, self.v
-        d.eos, v.eos = eos_token_id, eos_token_id
+        for eng in (d, v):      # captures happen here, not inside the threaded window
+            with torch.cuda.device(eng.device):
+                eng.ensure_graphs(eos_token_id)
         hidden_rows = []
         v_hidden = []
 

@@ -55,3 +55,28 @@ def test_event_frames_gpu_end_to_end(dev):
     if len(same_canvas) == 5:
         want = torch.stack([torch.from_numpy(cp.preprocess_image(f)) for f in host])
         assert torch.equal(px.float().cpu(), want.to(torch.bfloat16).float())
+
+
+def test_preprocess_frames_device_dispatch(dev):
+    """The frame preprocessing entry point gives the same pixels from the GPU kernel
+    and from the host path, and the verifier's processor uses it when given a device."""
+    from eventgpt_amd.ops import event_ops as eo
+    rng = np.random.default_rng(3)
+    frames = [rng.integers(0, 256, (120, 160, 3), dtype=np.uint8) for _ in range(4)]
+    g = eo.preprocess_frames(frames, dev, 56)
+    c = eo.preprocess_frames(frames, "cpu", 56)
+    assert g.is_cuda and g.shape == (4, 3, 56, 56) and g.dtype == torch.bfloat16
+    assert torch.equal(g.cpu(), c)
+    # unequal sizes fall back to the host path, still on the requested device
+    mixed = frames[:2] + [rng.integers(0, 256, (100, 90, 3), dtype=np.uint8)]
+    m = eo.preprocess_frames(mixed, dev, 56)
+    assert m.is_cuda and m.shape == (3, 3, 56, 56)
+    from eventgpt_amd.data.tokenizer import ByteTokenizer
+    from eventgpt_amd.models.video_llava import VideoLlavaConfig, VideoProcessor
+    cfg = VideoLlavaConfig.tiny()
+    proc = VideoProcessor(cfg, ByteTokenizer())
+    S = cfg.vision_config.image_size
+    out = proc("USER: <video>\nwhat? ASSISTANT:", frames, device=dev)
+    host = proc("USER: <video>\nwhat? ASSISTANT:", frames)
+    assert out["pixel_values_videos"].shape == (1, 4, 3, S, S) and out["pixel_values_videos"].is_cuda
+    assert torch.equal(out["pixel_values_videos"].float().cpu(), host["pixel_values_videos"].to(torch.bfloat16).float())

@@ -59,3 +59,33 @@ def test_live_runtimes(dev):
     assert r3.output_tokens == ref
     ev = P.evaluate_sd_outputs([r.as_dict(), r3.as_dict()], [{"tokens": ref, "total_ms": 50.0}] * 2)
     assert ev["lossless"] and ev["n"] == 2
+
+
+def test_prefill_hiding_runner_theory_mode(tmp_path):
+    from eventgpt_amd.benchmarks import prefill_hiding_bench as PH
+    res = PH.main(["--theory", "--egpt_prefill_ms", "100", "--vl_prefill_ms", "300", "--vl_token_ms", "20",
+                   "--egpt_token_ms", "10", "--verify_ms", "50", "--acceptance_rate", "0.5",
+                   "--max_new_tokens", "50", "--output_dir", str(tmp_path)])
+    row = next(t for t in res["theory"] if t["acceptance_rate"] == 0.5)
+    # window 200 ms -> 20 free drafts, 10 accepted, 200 ms saved of 1300; verify costs 50
+    assert row["free_drafts"] == 20 and row["accepted"] == 10 and row["time_saved_ms"] == 200
+    assert row["vl_baseline_ms"] == 1300 and row["sd_time_ms"] == 1150
+    assert abs(row["e2e_speedup"] - 1300 / 1150) < 1e-9
+    md = open(res["paths"]["md"]).read()
+    assert "Closed-form estimate" in md and "0.500" in md
+    agg = PH.aggregate([])
+    assert agg == {"n": 0}
+
+
+@pytest.mark.gpu
+def test_prefill_hiding_runner_gpu(tmp_path):
+    from eventgpt_amd.benchmarks import prefill_hiding_bench as PH
+    res = PH.main(["--random_init", "small", "--max_samples", "2", "--warmup", "1", "--max_new_tokens", "12",
+                   "--max_draft_tokens", "8", "--output_dir", str(tmp_path)])
+    agg = res["aggregate"]
+    assert agg["n"] == 2
+    for m in ("prefill_only", "prefill_then_verify", "aligned"):
+        assert m in agg, m
+        # every runtime returns the verifier's own greedy tokens
+        assert agg[m]["identical_outputs"] == 2, (m, agg[m])
+    assert agg["prefill_then_verify"]["lossless"] and "theory" in res

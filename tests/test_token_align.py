@@ -1,5 +1,7 @@
 """Token-level alignment modules, dataset IO, trainer, SD simulation, tokenizer tools (CPU)."""
 import json
+import math
+import os
 
 import pytest
 import torch
@@ -190,3 +192,53 @@ def test_tokenizer_alignment_tools():
     assert (rate, acc, n) == (1.0, 3, 3)
     rep = check_tokenizers(a, b, probes=("plain text",))
     assert rep["special_match"] and rep["probes"][0]["match_rate"] == 1.0 and rep["compatible"]
+
+
+def test_token_alignment_driver(tmp_path):
+    """extract (benchmark json / hidden store) -> train -> evaluate for each strategy."""
+    import json as _json
+
+    from eventgpt_amd.align import run_token_alignment as R
+    from eventgpt_amd.align.store import ChunkedHiddenStateWriter
+    torch.manual_seed(0)
+    V, H, N, S = 24, 16, 40, 10
+    # (a) token pairs from a benchmark-style json: target = (draft + 1) mod V, learnable map
+    rows = []
+    for i in range(N):
+        d = torch.randint(1, V, (S,)).tolist()
+        rows.append({"id": i, "egpt_token_ids": d, "llava_token_ids": [(x % (V - 1)) + 1 for x in d]})
+    bj = tmp_path / "bench.json"
+    bj.write_text(_json.dumps(rows))
+    cdir = str(tmp_path / "cached")
+    ds = R.main(["--mode", "extract", "--benchmark_json", str(bj), "--cached_dir", cdir, "--max_seq_len", "12"])
+    assert len(ds) == N and ds.draft_tokens.shape == (N, 12)
+    common = ["--cached_dir", cdir, "--device", "cpu", "--hidden_dim", "32", "--num_layers", "1",
+              "--num_attention_heads", "2", "--batch_size", "8", "--learning_rate", "5e-3"]
+    out = R.main(["--mode", "train", "--strategy", "token_adapter", "--num_epochs", "30", *common])
+    assert os.path.exists(out["checkpoint"])
+    res = R.main(["--mode", "evaluate", "--strategy", "token_adapter", *common,
+                  "--output_path", str(tmp_path / "eval.json")])
+    assert res["aligned"]["acceptance_rate"] > res["baseline"]["acceptance_rate"]
+    assert _json.load(open(tmp_path / "eval.json"))["strategy"] == "token_adapter"
+
+    # (b) hidden store -> projected tokens + hidden rows (+ logits) -> hidden-based strategies
+    w = ChunkedHiddenStateWriter(str(tmp_path / "store"), chunk_size=16)
+    W = torch.randn(V, H)
+    for i in range(N):
+        e = torch.randn(S, H)
+        w.add_sample(e, e + 0.1 * torch.randn(S, H), {"sample_idx": i, "question_idx": 0})
+    w.flush()
+    torch.save({"lm_head_weight": W}, tmp_path / "lm.pt")
+    hdir = str(tmp_path / "cached_h")
+    ds = R.main(["--mode", "extract", "--hidden_store", str(tmp_path / "store"), "--lm_head", str(tmp_path / "lm.pt"),
+                 "--cached_dir", hdir, "--max_seq_len", "10", "--with_logits"])
+    assert ds.draft_hidden.shape == (N, S, H) and ds.target_logits.shape == (N, S, V)
+    common = ["--cached_dir", hdir, "--device", "cpu", "--hidden_dim", "32", "--num_layers", "1",
+              "--num_attention_heads", "2", "--batch_size", "8", "--learning_rate", "2e-3", "--num_epochs", "3"]
+    for strat in ("eagle_fusion", "token_projection", "sequence_distillation", "logit_alignment"):
+        out = R.main(["--mode", "train", "--strategy", strat, *common])
+        assert os.path.exists(out["checkpoint"]), strat
+        assert all(math.isfinite(x) for x in out["stats"]["train_losses"]), strat
+        res = R.main(["--mode", "evaluate", "--strategy", strat, *common])
+        assert "aligned" in res and "baseline" in res, strat
+    assert "gamma_5" in res["gamma_sweep"] if strat == "eagle_fusion" else True
