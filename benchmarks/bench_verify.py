@@ -38,5 +38,10 @@ def ver():
     eng.pos.fill_(L); eng.step.fill_(1)
     eng.verify(draft, G)
 t_ver = timeit(ver)
+# same pass with the few-row fusion switched off (separate reduce / norm / rope / swiglu launches)
+eng.fused_rows = 0
+eng._verify_graphs.clear()
+t_unf = timeit(ver)
+print(f"verify(G={G}) unfused={t_unf:.3f} ms", flush=True)
 print(f"layers={cfg.num_hidden_layers} kv_len={L} decode_step={t_dec:.3f} ms  verify(G={G})={t_ver:.3f} ms  "
       f"ratio={t_ver / t_dec:.2f}", flush=True)

@@ -120,6 +120,80 @@ Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bia
   return y;
 }
 
+// ---- few-row projections: GEMM to fp32 split-K slabs + a fused consumer ----
+// partial [nslab, M, N] fp32 (nslab >= 1); the consumers below sum the slabs.
+Tensor linear_partial(const Tensor& x, const Tensor& w) {
+  check_bf16(x, "x"); check_bf16(w, "weight");
+  const int64_t K = x.size(-1), N = w.size(0);
+  TORCH_CHECK(w.dim() == 2 && w.size(1) == K, "linear_partial: K mismatch");
+  TORCH_CHECK(K % 64 == 0 && N % 8 == 0, "linear_partial: K % 64 == 0 and N % 8 == 0");
+  const int64_t M = x.numel() / K;
+  TORCH_CHECK(M >= 1, "linear_partial: empty input");
+  const int sk = evgpt::gemm_splitk((int)M, (int)N, (int)K);
+  Tensor ws = at::empty({sk, M, N}, x.options().dtype(at::kFloat));
+  const int used = evgpt::launch_gemm_partial(bptr(x), bptr(w), ws.data_ptr<float>(), (int)M, (int)N,
+                                              (int)K, (int)K, (int)K, cur_stream());
+  return used == sk ? ws : ws.narrow(0, 0, used);
+}
+
+// x_out = bf16(sum partial) + res; xn = RMSNorm(x_out) * norm_w when norm_w is given
+// (else xn is an empty tensor).  x_out may be `res` itself (in place).
+std::tuple<Tensor, Tensor> reduce_residual_norm(const Tensor& partial, const c10::optional<Tensor>& res,
+                                                const c10::optional<Tensor>& norm_w, double eps,
+                                                const c10::optional<Tensor>& out) {
+  check_f32(partial, "partial");
+  TORCH_CHECK(partial.dim() == 3, "partial must be [nslab, M, N]");
+  const int64_t S = partial.size(0), M = partial.size(1), N = partial.size(2);
+  TORCH_CHECK(N % 8 == 0, "reduce_residual_norm: N % 8 == 0");
+  auto bf = partial.options().dtype(at::kBFloat16);
+  Tensor x = out.has_value() ? *out : at::empty({M, N}, bf);
+  check_bf16(x, "out");
+  TORCH_CHECK(x.numel() == M * N, "reduce_residual_norm: out shape");
+  if (res.has_value()) { check_bf16(*res, "res"); TORCH_CHECK(res->numel() == M * N); }
+  Tensor xn;
+  if (norm_w.has_value()) {
+    check_bf16(*norm_w, "norm_w");
+    TORCH_CHECK(norm_w->numel() == N);
+    xn = at::empty({M, N}, bf);
+  } else {
+    xn = at::empty({0}, bf);
+  }
+  evgpt::launch_reduce_residual_norm(partial.data_ptr<float>(), (int)S, (int)M, (int)N, bptr_opt(res),
+                                     bptr_mut(x), bptr_opt(norm_w),
+                                     norm_w.has_value() ? bptr_mut(xn) : nullptr, (float)eps,
+                                     cur_stream());
+  return {x, xn};
+}
+
+Tensor reduce_swiglu(const Tensor& partial) {
+  check_f32(partial, "partial");
+  TORCH_CHECK(partial.dim() == 3 && partial.size(2) % 16 == 0, "partial must be [nslab, M, 2I]");
+  const int64_t S = partial.size(0), M = partial.size(1), I = partial.size(2) / 2;
+  Tensor y = at::empty({M, I}, partial.options().dtype(at::kBFloat16));
+  evgpt::launch_reduce_swiglu(partial.data_ptr<float>(), (int)S, M, (int)I, bptr_mut(y), cur_stream());
+  return y;
+}
+
+// partial [nslab, B*S, (Hq+2Hkv)*D] -> q_out [B,S,Hq*D] + cache rows at pos0[b]+s
+void reduce_rope_kv(const Tensor& partial, const Tensor& q_out, const Tensor& k_cache,
+                    const Tensor& v_cache, const Tensor& cos, const Tensor& sin, const Tensor& pos0,
+                    int64_t B, int64_t S, int64_t Hq, int64_t Hkv, int64_t D) {
+  check_f32(partial, "partial"); check_bf16(q_out, "q_out"); check_bf16(k_cache, "k_cache");
+  check_bf16(v_cache, "v_cache"); check_f32(cos, "cos"); check_f32(sin, "sin");
+  check_i32(pos0, "pos0");
+  TORCH_CHECK(partial.dim() == 3 && partial.size(1) == B * S && partial.size(2) == (Hq + 2 * Hkv) * D,
+              "reduce_rope_kv: partial must be [nslab, B*S, (Hq+2Hkv)*D]");
+  TORCH_CHECK(D % 16 == 0 && q_out.numel() == B * S * Hq * D && pos0.numel() == B);
+  TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(0) >= B && k_cache.size(1) == Hkv &&
+              k_cache.size(3) == D && v_cache.sizes() == k_cache.sizes() && k_cache.is_contiguous() &&
+              v_cache.is_contiguous(), "reduce_rope_kv: cache must be contiguous [B,Hkv,Lmax,D]");
+  TORCH_CHECK(cos.size(-1) == D / 2 && sin.size(-1) == D / 2 && cos.size(0) >= k_cache.size(2));
+  evgpt::launch_reduce_rope_kv(partial.data_ptr<float>(), (int)partial.size(0), bptr_mut(q_out),
+                               bptr_mut(k_cache), bptr_mut(v_cache), cos.data_ptr<float>(),
+                               sin.data_ptr<float>(), pos0.data_ptr<int>(), (int)B, (int)S, (int)Hq,
+                               (int)Hkv, (int)D, (int)k_cache.size(2), cur_stream());
+}
+
 Tensor swiglu(const Tensor& gate_up) {
   check_bf16(gate_up, "gate_up");
   const int64_t I2 = gate_up.size(-1);
@@ -526,6 +600,10 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("add_rmsnorm(Tensor x, Tensor res, Tensor w, float eps) -> (Tensor, Tensor)", &add_rmsnorm);
   m.def("layernorm(Tensor x, Tensor w, Tensor? b, float eps) -> Tensor", &layernorm);
   m.def("linear(Tensor x, Tensor w, Tensor? bias, Tensor? res, int act, bool out_f32) -> Tensor", &linear);
+  m.def("linear_partial(Tensor x, Tensor w) -> Tensor", &linear_partial);
+  m.def("reduce_residual_norm(Tensor partial, Tensor? res, Tensor? norm_w, float eps, Tensor(a!)? out) -> (Tensor, Tensor)", &reduce_residual_norm);
+  m.def("reduce_swiglu(Tensor partial) -> Tensor", &reduce_swiglu);
+  m.def("reduce_rope_kv(Tensor partial, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos0, int B, int S, int Hq, int Hkv, int D) -> ()", &reduce_rope_kv);
   m.def("swiglu(Tensor gate_up) -> Tensor", &swiglu);
   m.def("rope(Tensor x, Tensor positions, Tensor cos, Tensor sin) -> Tensor", &rope);
   m.def("attention(Tensor q, Tensor k, Tensor v, bool causal, float scale, int q_offset) -> Tensor", &attention);

@@ -30,6 +30,8 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
                       const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
                       float* amax_val, int* amax_idx, float* splitk_ws, int splitk,
                       hipStream_t st);
+int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M, int N, int K,
+                        int lda, int ldw, hipStream_t st);
 int gemm_splitk(int M, int N, int K);   // planned split count (1 = none); ws = splitk*M*N floats
 void gemm_force_splitk(int sk);         // 0 = automatic; for tuning runs
 
@@ -78,6 +80,17 @@ void launch_patchify(const bf16_t* px, bf16_t* out, int T, int C, int S, int P, 
 void launch_vit_embed_ln(const bf16_t* tok, const bf16_t* cls, const bf16_t* pos, const bf16_t* w,
                          const bf16_t* b, bf16_t* out, int T, int N, int H, float eps,
                          hipStream_t st);
+
+// ---- skinny.hip (consumers of split-K partials)
+void launch_reduce_residual_norm(const float* partial, int nslab, int M, int N, const bf16_t* res,
+                                 bf16_t* x_out, const bf16_t* norm_w, bf16_t* xn_out, float eps,
+                                 hipStream_t st);
+void launch_reduce_swiglu(const float* partial, int nslab, long long M, int I, bf16_t* out,
+                          hipStream_t st);
+void launch_reduce_rope_kv(const float* partial, int nslab, bf16_t* q_out, bf16_t* k_cache,
+                           bf16_t* v_cache, const float* cos_tab, const float* sin_tab,
+                           const int* pos0, int B, int S, int Hq, int Hkv, int D, int l_max,
+                           hipStream_t st);
 
 // ---- attn_decode.hip
 void launch_attn_decode(const bf16_t* q, const bf16_t* k_cache, const bf16_t* v_cache,

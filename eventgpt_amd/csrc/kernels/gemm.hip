@@ -50,6 +50,7 @@ struct GemmParams {
   // second launch sums the slabs and applies the epilogue.
   int splitk, k_per_split;
   float* partial;
+  int raw_partial;     // store the fp32 slab even when splitk == 1 (a fused consumer sums it)
 };
 
 // wait until at most `n` of this wave's direct-to-LDS loads are still in flight
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   }
 
   // ---- epilogue: lane holds C[m][n .. n+3]
-  if (p.splitk > 1) {
+  if (p.splitk > 1 || p.raw_partial) {
     float* slab = p.partial + static_cast<size_t>(ksplit) * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -364,7 +365,7 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
                       float* amax_val, int* amax_idx, float* splitk_ws, int splitk,
                       hipStream_t st) {
   GemmParams p{A, W, C, bias, res, Cf, M, N, K, lda, ldw, ldc, act, amax_val, amax_idx, 1, K,
-               nullptr};
+               nullptr, 0};
   if (splitk > 1 && splitk_ws && !amax_val) {
     const int ksteps = K / 64;
     p.splitk = splitk;
@@ -385,6 +386,28 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
   }
+}
+
+// Projection that stops at the fp32 split-K slabs partial[nslab][M][N]; returns
+// nslab (>= 1).  `partial` holds gemm_splitk(M, N, K) * M * N floats.
+int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M, int N, int K,
+                        int lda, int ldw, hipStream_t st) {
+  GemmParams p{A, W, nullptr, nullptr, nullptr, nullptr, M, N, K, lda, ldw, N, ACT_NONE, nullptr,
+               nullptr, 1, K, partial, 1};
+  const int splitk = gemm_splitk(M, N, K);
+  if (splitk > 1) {
+    const int ksteps = K / 64;
+    p.k_per_split = ((ksteps + splitk - 1) / splitk) * 64;
+    p.splitk = (K + p.k_per_split - 1) / p.k_per_split;
+  }
+  switch (pick_cfg(M, N)) {
+    case CFG_128x128: launch_cfg<128, 128, 2, 2, 2>(p, st); break;
+    case CFG_64x128: launch_cfg<64, 128, 2, 2, 3>(p, st); break;
+    case CFG_64x64: launch_cfg<64, 64, 2, 2, 4>(p, st); break;
+    case CFG_32x64: launch_cfg<32, 64, 1, 4, 4>(p, st); break;
+    default: launch_cfg<32, 128, 1, 4, 4>(p, st); break;
+  }
+  return p.splitk;
 }
 
 }  // namespace evgpt

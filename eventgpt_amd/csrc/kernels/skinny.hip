@@ -1,0 +1,176 @@
+// Consumers of split-K GEMM partials for the few-row regime (speculative verify,
+// batched decode with <= 32 rows).
+//
+// With a handful of activation rows a projection is weight streaming: the GEMM
+// splits K over blocks to fill the chip and leaves fp32 slabs
+// partial[s][M][N].  Summing the slabs is a pass over M*N floats anyway, so the
+// op that follows the projection rides on that pass instead of being its own
+// launch and its own round trip through HBM:
+//   * o_proj / down_proj : sum -> + residual -> (RMSNorm of the next block)
+//   * gate_up            : sum -> SiLU(gate) * up
+//   * qkv                : sum -> RoPE -> q rows / KV-cache append
+// Each consumer rounds the summed projection to bf16 first, exactly where the
+// unfused GEMM epilogue would have, so fused and unfused paths agree bit for bit.
+#include "common.h"
+#include "../evgpt_kernels.h"
+
+namespace evgpt {
+
+// 8 consecutive columns starting at element e0 of the [M][N] slab, summed over
+// the slabs in slab order and rounded to bf16 (returned as 4 packed pairs).
+__device__ __forceinline__ u32x4_t sum8_bf16(const float* __restrict__ partial, size_t slab,
+                                             int nslab, size_t e0) {
+  f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nslab; ++s) {
+    const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(partial + s * slab + e0);
+    const f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(partial + s * slab + e0 + 4);
+    a[0] += t0[0]; a[1] += t0[1]; a[2] += t0[2]; a[3] += t0[3];
+    b[0] += t1[0]; b[1] += t1[1]; b[2] += t1[2]; b[3] += t1[3];
+  }
+  return u32x4_t{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
+                 pack_bf16x2(b[2], b[3])};
+}
+
+// x_out[m] = bf16(sum) + res[m];  xn_out[m] = RMSNorm(x_out[m]) * norm_w  (if norm_w)
+// One block per row.  x_out may alias res.
+__global__ __launch_bounds__(256) void reduce_residual_norm_kernel(
+    const float* __restrict__ partial, int nslab, int M, int N, const bf16_t* res, bf16_t* x_out,
+    const bf16_t* __restrict__ norm_w, bf16_t* __restrict__ xn_out, float eps) {
+  __shared__ float red[16];
+  const int m = blockIdx.x;
+  const size_t slab = static_cast<size_t>(M) * N, base = static_cast<size_t>(m) * N;
+  const int nchunk = N >> 3;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    u32x4_t v = sum8_bf16(partial, slab, nslab, base + c * 8);
+    if (res) {
+      const u32x4_t r = load16(res + base + c * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        v[i] = pack_bf16x2(bf16lo(v[i]) + bf16lo(r[i]), bf16hi(v[i]) + bf16hi(r[i]));
+    }
+    *reinterpret_cast<u32x4_t*>(x_out + base + c * 8) = v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float lo = bf16lo(v[i]), hi = bf16hi(v[i]);
+      ss += lo * lo + hi * hi;
+    }
+  }
+  if (!norm_w) return;  // block-uniform
+  ss = block_sum(ss, red);
+  const float rstd = rsqrtf(ss / static_cast<float>(N) + eps);
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    const u32x4_t v = load16(x_out + base + c * 8);  // this thread's own stores
+    const u32x4_t g = load16(norm_w + c * 8);
+    u32x4_t o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float lo = bf16_to_f32(f32_to_bf16(bf16lo(v[i]) * rstd)) * bf16lo(g[i]);
+      const float hi = bf16_to_f32(f32_to_bf16(bf16hi(v[i]) * rstd)) * bf16hi(g[i]);
+      o[i] = pack_bf16x2(lo, hi);
+    }
+    *reinterpret_cast<u32x4_t*>(xn_out + base + c * 8) = o;
+  }
+}
+
+// partial [nslab][M][2I] laid out [gate | up] -> out [M][I]
+__global__ __launch_bounds__(256) void reduce_swiglu_kernel(const float* __restrict__ partial,
+                                                            int nslab, long long M, int I,
+                                                            bf16_t* __restrict__ out) {
+  const int cpr = I >> 3;
+  const long long total = M * cpr;
+  const size_t slab = static_cast<size_t>(M) * 2 * I;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const long long m = i / cpr;
+    const int c = static_cast<int>(i % cpr);
+    const u32x4_t g = sum8_bf16(partial, slab, nslab, static_cast<size_t>(m) * 2 * I + c * 8);
+    const u32x4_t u = sum8_bf16(partial, slab, nslab, static_cast<size_t>(m) * 2 * I + I + c * 8);
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = pack_bf16x2(silu_f(bf16lo(g[j])) * bf16lo(u[j]), silu_f(bf16hi(g[j])) * bf16hi(u[j]));
+    *reinterpret_cast<u32x4_t*>(out + m * I + c * 8) = o;
+  }
+}
+
+// partial [nslab][B*S][(Hq+2Hkv)*D] -> q_out [B][S][Hq*D], k/v cache rows at pos0[b]+s.
+// Thread = one 8-wide chunk of the first half of a head and its rotate-half partner.
+__global__ __launch_bounds__(256) void reduce_rope_kv_kernel(
+    const float* __restrict__ partial, int nslab, bf16_t* __restrict__ q_out,
+    bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, const float* __restrict__ cos_tab,
+    const float* __restrict__ sin_tab, const int* __restrict__ pos0, int S, int Hq, int Hkv, int D,
+    int l_max) {
+  const int hh = D >> 1, cph = hh >> 3;
+  const int heads = Hq + 2 * Hkv;
+  const int per_tok = heads * cph;
+  const int b = blockIdx.y, B = gridDim.y;
+  const size_t slab = static_cast<size_t>(B) * S * heads * D;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < static_cast<long long>(S) * per_tok;
+       i += gridDim.x * 256ll) {
+    const int s = static_cast<int>(i / per_tok);
+    const int rem = static_cast<int>(i % per_tok);
+    const int h = rem / cph, c = rem % cph;
+    int pos = (pos0 ? pos0[b] : 0) + s;
+    // device-side positions: a row that would land outside the cache is dropped
+    const bool in_cache = pos >= 0 && pos < l_max;
+    pos = pos < 0 ? 0 : (pos >= l_max ? l_max - 1 : pos);
+    if (h >= Hq && !in_cache) continue;
+    const size_t src = (static_cast<size_t>(b) * S + s) * heads * D + h * D + c * 8;
+    const u32x4_t a = sum8_bf16(partial, slab, nslab, src);
+    const u32x4_t bb = sum8_bf16(partial, slab, nslab, src + hh);
+    bf16_t* dst;
+    if (h < Hq) {
+      dst = q_out + (static_cast<size_t>(b) * S + s) * Hq * D + h * D;
+    } else if (h < Hq + Hkv) {
+      dst = k_cache + ((static_cast<size_t>(b) * Hkv + (h - Hq)) * l_max + pos) * D;
+    } else {
+      dst = v_cache + ((static_cast<size_t>(b) * Hkv + (h - Hq - Hkv)) * l_max + pos) * D;
+      *reinterpret_cast<u32x4_t*>(dst + c * 8) = a;
+      *reinterpret_cast<u32x4_t*>(dst + hh + c * 8) = bb;
+      continue;
+    }
+    const float* cs = cos_tab + static_cast<size_t>(pos) * hh + c * 8;
+    const float* sn = sin_tab + static_cast<size_t>(pos) * hh + c * 8;
+    u32x4_t o1, o2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float c0 = cs[2 * j], c1 = cs[2 * j + 1], s0 = sn[2 * j], s1 = sn[2 * j + 1];
+      const float x1l = bf16lo(a[j]), x1h = bf16hi(a[j]), x2l = bf16lo(bb[j]), x2h = bf16hi(bb[j]);
+      o1[j] = pack_bf16x2(x1l * c0 - x2l * s0, x1h * c1 - x2h * s1);
+      o2[j] = pack_bf16x2(x2l * c0 + x1l * s0, x2h * c1 + x1h * s1);
+    }
+    *reinterpret_cast<u32x4_t*>(dst + c * 8) = o1;
+    *reinterpret_cast<u32x4_t*>(dst + hh + c * 8) = o2;
+  }
+}
+
+void launch_reduce_residual_norm(const float* partial, int nslab, int M, int N, const bf16_t* res,
+                                 bf16_t* x_out, const bf16_t* norm_w, bf16_t* xn_out, float eps,
+                                 hipStream_t st) {
+  hipLaunchKernelGGL(reduce_residual_norm_kernel, dim3(M), dim3(256), 0, st, partial, nslab, M, N,
+                     res, x_out, norm_w, xn_out, eps);
+}
+
+void launch_reduce_swiglu(const float* partial, int nslab, long long M, int I, bf16_t* out,
+                          hipStream_t st) {
+  const long long work = M * (I / 8);
+  int blocks = static_cast<int>((work + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(reduce_swiglu_kernel, dim3(blocks), dim3(256), 0, st, partial, nslab, M, I,
+                     out);
+}
+
+void launch_reduce_rope_kv(const float* partial, int nslab, bf16_t* q_out, bf16_t* k_cache,
+                           bf16_t* v_cache, const float* cos_tab, const float* sin_tab,
+                           const int* pos0, int B, int S, int Hq, int Hkv, int D, int l_max,
+                           hipStream_t st) {
+  const long long work = static_cast<long long>(S) * (Hq + 2 * Hkv) * (D / 16);
+  int blocks = static_cast<int>((work + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(reduce_rope_kv_kernel, dim3(blocks, B), dim3(256), 0, st, partial, nslab,
+                     q_out, k_cache, v_cache, cos_tab, sin_tab, pos0, S, Hq, Hkv, D, l_max);
+}
+
+}  // namespace evgpt

@@ -222,6 +222,8 @@ class TensorParallelEngine(GenerationEngine):
     def _forward_rows(self, embeds, batch, pos0):
         raw = self.raw
         S = embeds.shape[0]
+        if self._few_rows_ok(S):
+            return self._forward_rows_fused(embeds, batch, pos0)
         x = embeds.to(torch.bfloat16).contiguous().view(1, S, self.H)
         kv_len = pos0 + S
         q = torch.empty(1, S, self.Hq, self.D, dtype=torch.bfloat16, device=self.device)
@@ -256,6 +258,23 @@ class TensorParallelEngine(GenerationEngine):
         # batched decode (e.g. 32 streams): M = B rows through the MFMA GEMM
         B = self.B
         x = self.x
+        if self._few_rows_ok(B):
+            # one engine, <= 32 streams: the split-K consumers carry RoPE/cache append,
+            # residual + next norm and SwiGLU (no separate launches for them)
+            n = len(self.layers)
+            xn = raw.rmsnorm(x, self.layers[0].norm1, self.eps)
+            for i, l in enumerate(self.layers):
+                raw.reduce_rope_kv(raw.linear_partial(xn, l.w_qkv), self.q, l.k_cache, l.v_cache,
+                                   self.cos, self.sin, self.pos, B, 1, self.Hq, self.Hkv, self.D)
+                raw.decode_attn(self.q, l.k_cache, l.v_cache, self.attn, self.part_o, self.part_ml,
+                                self.pos, self.nsplit, self.scale)
+                x, xn = raw.reduce_residual_norm(raw.linear_partial(self.attn, l.w_o), x, l.norm2,
+                                                 self.eps, None)
+                h = raw.reduce_swiglu(raw.linear_partial(xn, l.w_gate_up))
+                nxt = self.layers[i + 1].norm1 if i + 1 < n else None
+                x, xn = raw.reduce_residual_norm(raw.linear_partial(h, l.w_down), x, nxt, self.eps, None)
+            self.x.copy_(x)
+            return
         for l in self.layers:
             qkv = raw.linear(raw.rmsnorm(x, l.norm1, self.eps), l.w_qkv, None, None, 0, False)
             raw.prefill_rope_kv(qkv.view(B, 1, -1), self.q.view(B, 1, -1), l.k_cache, l.v_cache,

@@ -191,6 +191,36 @@ class GenerationEngine:
             self._logits_and_commit(greedy=(select == "greedy"))
         return x[0] if return_hidden else None
 
+    # Row counts up to this take the few-row path: projections stop at their fp32
+    # split-K slabs and the op that follows (RoPE + cache append, residual + next
+    # RMSNorm, SwiGLU) is done by the kernel that sums the slabs.
+    fused_rows = 32
+
+    def _few_rows_ok(self, rows: int) -> bool:
+        return (4 < rows <= self.fused_rows and self.tp_world == 1 and self.H % 64 == 0
+                and self.I % 64 == 0 and (self.Hq * self.D) % 64 == 0)
+
+    def _forward_rows_fused(self, embeds: torch.Tensor, batch: int, pos0: torch.Tensor) -> torch.Tensor:
+        raw = self.raw
+        S = embeds.shape[0]
+        x = embeds.to(torch.bfloat16).contiguous().view(S, self.H)
+        kv_len = pos0 + S
+        q = torch.empty(1, S, self.Hq, self.D, dtype=torch.bfloat16, device=self.device)
+        o = torch.empty_like(q)
+        xn = raw.rmsnorm(x, self.layers[0].norm1, self.eps)
+        n = len(self.layers)
+        for i, l in enumerate(self.layers):
+            kc, vc = l.k_cache[batch:batch + 1], l.v_cache[batch:batch + 1]
+            raw.reduce_rope_kv(raw.linear_partial(xn, l.w_qkv), q, kc, vc, self.cos, self.sin, pos0,
+                               1, S, self.Hq, self.Hkv, self.D)
+            raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
+            x, xn = raw.reduce_residual_norm(raw.linear_partial(o.view(S, self.Hq * self.D), l.w_o),
+                                             x, l.norm2, self.eps, None)
+            h = raw.reduce_swiglu(raw.linear_partial(xn, l.w_gate_up))
+            nxt = self.layers[i + 1].norm1 if i + 1 < n else None
+            x, xn = raw.reduce_residual_norm(raw.linear_partial(h, l.w_down), x, nxt, self.eps, None)
+        return x.view(1, S, self.H)
+
     def _forward_rows(self, embeds: torch.Tensor, batch: int, pos0: torch.Tensor) -> torch.Tensor:
         """All decoder layers over ``embeds [S, H]`` placed at cache positions
         ``pos0[0] .. pos0[0]+S-1`` of sequence ``batch`` (``pos0`` is a device int32
@@ -198,6 +228,8 @@ class GenerationEngine:
         final norm.  Does not touch the position counters."""
         raw = self.raw
         S = embeds.shape[0]
+        if self._few_rows_ok(S):
+            return self._forward_rows_fused(embeds, batch, pos0)
         x = embeds.to(torch.bfloat16).contiguous().view(1, S, self.H)
         kv_len = pos0 + S
         q = torch.empty(1, S, self.Hq, self.D, dtype=torch.bfloat16, device=self.device)

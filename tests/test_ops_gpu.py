@@ -165,3 +165,71 @@ def test_attention_against_cache(dev, D, Hq, Hkv, Sq, kv, Lmax):
     v = vc[:, :, :kv].transpose(1, 2).float().repeat_interleave(rep, dim=2)
     ref = reference.attention(q.float(), k, v, causal=True, q_offset=kv - Sq)
     assert torch.allclose(out.float(), ref, atol=2e-2, rtol=2e-2), (out.float() - ref).abs().max()
+
+
+# ---- few-row projections: split-K slabs + fused consumers (verify / batched decode)
+@pytest.mark.parametrize("M,N,K", [(6, 4096, 4096), (32, 1536, 512), (2, 4096, 11008), (17, 22016, 4096)])
+def test_linear_partial_sums_to_linear(dev, M, N, K):
+    raw = _hip().raw
+    x, w = _rand(M, K, dev=dev, scale=0.5), _rand(N, K, dev=dev, scale=0.05, seed=1)
+    part = raw.linear_partial(x, w)
+    assert part.dtype == torch.float32 and part.shape[1:] == (M, N) and part.shape[0] >= 1
+    want = x.float() @ w.float().T
+    _close(part.sum(0), want, 2e-2 * math.sqrt(K / 512), 2e-2)
+
+
+@pytest.mark.parametrize("M", [2, 6, 32])
+def test_reduce_consumers_match_unfused_bitwise(dev, M):
+    """Each consumer equals GEMM -> bf16 -> the standalone op, bit for bit.  (Up to 4
+    rows the standalone projection is the GEMV, whose summation order differs: there
+    the comparison is a tolerance.)"""
+    raw = _hip().raw
+
+    def same(a, b):
+        if M > 4:
+            return torch.equal(a, b)
+        _close(a, b, 3e-2, 3e-2)
+        return True
+    H, I, Hq, Hkv, D, Lmax = 512, 1408, 4, 4, 128, 64
+    x = _rand(M, H, dev=dev, scale=0.5)
+    res = _rand(M, H, dev=dev, seed=5)
+    norm_w = (1 + 0.1 * torch.randn(H, device=dev)).to(torch.bfloat16)
+    # residual + norm after an H->H projection
+    w_o = _rand(H, H, dev=dev, scale=0.05, seed=2)
+    y = raw.linear(x, w_o, None, res, 0, False)
+    yn = raw.rmsnorm(y, norm_w, 1e-5)
+    fx, fxn = raw.reduce_residual_norm(raw.linear_partial(x, w_o), res, norm_w, 1e-5, None)
+    assert same(fx, y) and same(fxn, yn)
+    fx2, empty = raw.reduce_residual_norm(raw.linear_partial(x, w_o), res, None, 1e-5, None)
+    assert same(fx2, y) and empty.numel() == 0
+    # in place on the residual
+    r2 = res.clone()
+    raw.reduce_residual_norm(raw.linear_partial(x, w_o), r2, None, 1e-5, r2)
+    assert same(r2, y)
+    # SwiGLU after the gate|up projection
+    w_gu = _rand(2 * I, H, dev=dev, scale=0.05, seed=3)
+    want = raw.swiglu(raw.linear(x, w_gu, None, None, 0, False))
+    assert same(raw.reduce_swiglu(raw.linear_partial(x, w_gu)), want)
+    # RoPE + cache append after the qkv projection: M rows as one sequence ...
+    w_qkv = _rand((Hq + 2 * Hkv) * D, H, dev=dev, scale=0.05, seed=4)
+    from eventgpt_amd import ops
+    cos, sin = ops.rope_tables(Lmax, D, 10000.0, dev)
+    cos, sin = cos.contiguous(), sin.contiguous()
+    pos0 = torch.tensor([5], dtype=torch.int32, device=dev)
+    qkv = raw.linear(x, w_qkv, None, None, 0, False)
+
+    def run(fused, B, S, pos):
+        q = torch.zeros(B, S, Hq * D, dtype=torch.bfloat16, device=dev)
+        kc = torch.zeros(B, Hkv, Lmax, D, dtype=torch.bfloat16, device=dev)
+        vc = torch.zeros_like(kc)
+        if fused:
+            raw.reduce_rope_kv(raw.linear_partial(x, w_qkv), q, kc, vc, cos, sin, pos, B, S, Hq, Hkv, D)
+        else:
+            raw.prefill_rope_kv(qkv.view(B, S, -1), q, kc, vc, cos, sin, pos, Hq, Hkv, D)
+        return q, kc, vc
+    for a, b in zip(run(True, 1, M, pos0), run(False, 1, M, pos0)):
+        assert same(a, b)
+    # ... and as M sequences of one row each with their own positions (batched decode)
+    posb = (torch.arange(M, device=dev, dtype=torch.int32) * 3) % (Lmax + 4) - 1   # incl. out-of-cache rows
+    for a, b in zip(run(True, M, 1, posb), run(False, M, 1, posb)):
+        assert same(a, b)
