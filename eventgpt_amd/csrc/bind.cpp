@@ -243,7 +243,6 @@ Tensor attention(const Tensor& q, const Tensor& k, const Tensor& v, bool causal,
   long long s[12];
   fill_strides_bshd(q, s); fill_strides_bshd(k, s + 3); fill_strides_bshd(v, s + 6);
   fill_strides_bshd(o, s + 9);
-  for (int i = 0; i < 9; ++i) TORCH_CHECK(s[i] % 8 == 0 || s[i] == 0 || true);
   TORCH_CHECK(q.stride(1) % 8 == 0 && q.stride(2) % 8 == 0 && k.stride(1) % 8 == 0 &&
               k.stride(2) % 8 == 0 && v.stride(1) % 8 == 0 && v.stride(2) % 8 == 0,
               "attention: strides must keep 16-byte alignment");

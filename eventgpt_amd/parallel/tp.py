@@ -94,6 +94,24 @@ def _all_reduce(t: torch.Tensor, group) -> torch.Tensor:
     return t
 
 
+def gather_vocab_shards(local_logits: torch.Tensor, v_total: int, group) -> torch.Tensor:
+    """Full ``[B, v_total]`` logits from equally sized (zero/-inf padded) per-rank shards."""
+    world = dist.get_world_size(group) if (group is not None and dist.is_initialized()) else 1
+    if world == 1:
+        return local_logits[:, :v_total]
+    t = local_logits.contiguous()
+    if dist.get_backend(group) == "gloo" and t.is_cuda:   # gloo only ever sees host tensors
+        host = t.cpu()
+        bufs = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(bufs, host, group=group)
+        parts = [b.to(t.device) for b in bufs]
+    else:
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=group)
+    vl = t.shape[1]
+    return torch.cat([p[:, :min(vl, max(v_total - r * vl, 0))] for r, p in enumerate(parts)], dim=1)
+
+
 def distributed_argmax(local_val: torch.Tensor, local_idx: torch.Tensor, group) -> torch.Tensor:
     """Global argmax from per-rank ``(max value, global index)`` pairs ``[B]``; ties go to
     the lowest index.  Only 8 bytes per row per rank cross the fabric."""
@@ -185,6 +203,8 @@ class TensorParallelEngine(GenerationEngine):
     def __init__(self, model, group=None, max_len: int = 2048, max_batch: int = 1, **kw):
         self._group_arg = group
         super().__init__(model, max_len=max_len, max_batch=max_batch, **kw)
+        if self.tp_world > 1:   # samplers read the gathered, full-vocabulary rows
+            self.logits = torch.zeros(self.B, self.v_total, dtype=torch.float32, device=self.device)
 
     def _setup_parallel(self) -> None:
         g = self._group_arg
@@ -295,8 +315,10 @@ class TensorParallelEngine(GenerationEngine):
             logits[:, n_valid:] = float("-inf")
         if not greedy or want_logits:
             if self.tp_world > 1:
-                raise NotImplementedError("sampling needs the full logits; gather them first")
-            self.logits.copy_(logits[:, :self.logits.shape[1]])
+                # a sampler needs every rank's vocabulary shard: gather them in rank order
+                self.logits.copy_(gather_vocab_shards(logits, self.v_total, self.tp_group))
+            else:
+                self.logits.copy_(logits[:, :self.logits.shape[1]])
         if greedy:
             # own argmax kernel + gather: graph-safe (no library reduction in the capture)
             idx = raw.argmax_rows(logits)

@@ -9,7 +9,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eventgpt_amd.models import EventChatConfig, EventChatModel  # noqa: E402
 from eventgpt_amd.parallel.dist import init_distributed, shutdown  # noqa: E402
-from eventgpt_amd.parallel.tp import TensorParallelDecoder  # noqa: E402
+from eventgpt_amd.parallel.tp import TensorParallelDecoder, gather_vocab_shards, shard_vocab  # noqa: E402
 
 
 def main(out_path):
@@ -26,8 +26,12 @@ def main(out_path):
     h = tp(x)
     tok = tp.greedy_next(h[:, -1])
     err = (h - full).abs().max().item()
+    # vocabulary shards (203 rows do not divide evenly) gathered back to full logits
+    w_local, _ = shard_vocab(model.lm_head.weight.data, info.rank, info.world)
+    logits = gather_vocab_shards(full[:, -1] @ w_local.T, 203, dist.group.WORLD)
+    gerr = (logits - model.lm_head(full[:, -1])).abs().max().item() if logits.shape == (2, 203) else 1e9
     gathered = [None] * info.world
-    dist.all_gather_object(gathered, {"err": err, "tok": tok.tolist()})
+    dist.all_gather_object(gathered, {"err": err, "tok": tok.tolist(), "gather_err": gerr})
     if info.rank == 0:
         json.dump({"ranks": gathered, "want_tok": full_tok.tolist(),
                    "i_local": tp.shards[0][2].shape[0] // 2}, open(out_path, "w"))

@@ -107,3 +107,47 @@ def test_lm_head_extractor(tmp_path):
     assert torch.equal(blob["lm_head_weight"], m.lm_head.weight.data) and blob["vocab_size"] == 320
     from eventgpt_amd.eval.acceptance import load_lm_head
     assert load_lm_head(out).shape == (320, 64)
+
+
+def test_monitor_progress_wait_and_chain(tmp_path):
+    import os as _os
+    import subprocess as _sp
+    import sys as _sys
+
+    from eventgpt_amd.align.store import ChunkedHiddenStateWriter
+    from eventgpt_amd.pipeline import monitor as M
+    store = str(tmp_path / "store")
+    assert M.extraction_progress(store)["exists"] is False
+    w = ChunkedHiddenStateWriter(store, chunk_size=4)
+    for i in range(10):
+        w.add_sample(torch.randn(5, 8), torch.randn(5, 8), {"sample_idx": i, "question_idx": 0})
+    w.flush()
+    p = M.extraction_progress(store, expected=10)
+    assert p["total_samples"] == 10 and p["n_chunks"] == 3 and p["complete"]
+    assert "10 / 10 samples" in M.format_progress(p)
+    # complete store: returns at once
+    assert M.wait_for_extraction(store, 10, poll_s=0.01, out=lambda *_: None)["status"] == "complete"
+    # short of the target with a watched process that has exited
+    child = _sp.Popen([_sys.executable, "-c", "pass"])
+    child.wait()
+    r = M.wait_for_extraction(store, 50, pid=child.pid, poll_s=0.01, out=lambda *_: None)
+    assert r["status"] == "extractor_exited" and r["total_samples"] == 10
+    # short of the target, nothing watched: times out (sleep is injected, nothing really waits)
+    naps = []
+    r = M.wait_for_extraction(store, 50, poll_s=1.0, timeout_s=0.0, out=lambda *_: None, sleep=naps.append)
+    assert r["status"] == "timeout"
+    assert M.pid_alive(_os.getpid()) and not M.pid_alive(child.pid)
+    # the chain stops at the first failing stage
+    calls = []
+
+    def fake_runner(cmd, log, out):
+        calls.append(cmd)
+        return 0 if "--adapter_level" in cmd and cmd[cmd.index("--adapter_level") + 1] == "1" else 3
+    res = M.auto_train(store, None, [1, 2, 3], str(tmp_path / "tasks"), runner=fake_runner, out=lambda *_: None)
+    assert [r["level"] for r in res] == ["L1", "L2"] and res[1]["train_rc"] == 3 and len(calls) == 2
+    # and really trains + evaluates one level end to end on the CPU
+    res = M.auto_train(store, store, [1], str(tmp_path / "tasks"), str(tmp_path / "logs"), num_epochs=1,
+                       batch_size=4, extra_train_args=["--hidden_dim", "8", "--bottleneck_dim", "4"], cpu=True,
+                       out=lambda *_: None)
+    assert res[0]["train_rc"] == 0 and res[0]["eval_rc"] == 0, open(tmp_path / "logs" / "train_L1.log").read()[-800:]
+    assert _os.path.exists(_os.path.join(res[0]["run_dir"], "eval", "acceptance_metrics.json"))

@@ -25,6 +25,7 @@ def test_tp_decoder_matches_full_model(tmp_path, world, port):
     for rk in got["ranks"]:
         assert rk["err"] < 1e-4, rk
         assert rk["tok"] == got["want_tok"]
+        assert rk["gather_err"] < 1e-4, rk
     assert got["i_local"] % 64 == 0          # intermediate shard padded for the MFMA GEMM
 
 
