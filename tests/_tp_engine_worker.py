@@ -1,0 +1,68 @@
+"""Worker for the GPU tensor-parallel engine test: two ranks share GPU 0, the process
+group is gloo (host tensors only), graphs are off (a host copy cannot be captured)."""
+import json
+import os
+import sys
+
+os.environ["LOCAL_RANK"] = "0"          # every rank of this test drives the one GPU of the box
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eventgpt_amd.models import EventChatConfig, EventChatModel  # noqa: E402
+from eventgpt_amd.parallel.dist import init_distributed, shutdown  # noqa: E402
+from eventgpt_amd.parallel.tp import TensorParallelEngine  # noqa: E402
+
+
+def main(out_path):
+    info = init_distributed(backend="gloo", use_gpu=True)
+    dev = info.device
+    cfg = EventChatConfig(vocab_size=515, hidden_size=512, intermediate_size=1408, num_hidden_layers=2,
+                          num_attention_heads=4, max_position_embeddings=512)
+    model = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=3)
+    B = 2
+    prompts = [(torch.randn(20 + 3 * b, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(b))
+                * 0.5).to(torch.bfloat16) for b in range(B)]
+    single = model.engine(max_len=256, max_new_tokens=32, use_graph=False)
+    want, want_x = [], []
+    for p in prompts:
+        single.eos = -1
+        single.reset()
+        single.prefill(p)
+        xs = [single.x[0].float().clone()]          # next-step input embedding after the prefill commit
+        single._layers_step()
+        xs.append(single.x[0].float().clone())      # residual stream after the first decode step's layers
+        single._logits_and_commit(greedy=True)
+        want_x.append(xs)
+        want.append(single.generate(p, 8, eos_token_id=-1).tolist())
+    print(f"rank {info.rank}: single-engine reference done", flush=True)
+    eng = TensorParallelEngine(model, dist.group.WORLD, max_len=256, max_batch=B, max_new_tokens=32,
+                               use_graph=False)
+    eng.eos = -1
+    eng.prefill_batch(prompts)
+    cos = torch.nn.functional.cosine_similarity
+    first_tok = [int(eng.out_tokens[b, 0]) for b in range(B)]
+    c0 = [float(cos(eng.x[b].float(), want_x[b][0], dim=0)) for b in range(B)]
+    eng._layers_step()
+    c1 = [float(cos(eng.x[b].float(), want_x[b][1], dim=0)) for b in range(B)]
+    eng._logits_and_commit(greedy=True)
+    for _ in range(6):
+        eng.decode_step(True)
+    torch.cuda.synchronize()
+    got = [eng.tokens(b).tolist() for b in range(B)]
+    # sampling path: every rank must hold the same full-vocabulary logits row
+    eng._logits_and_commit(greedy=False)
+    row = eng.logits[0].cpu()
+    rows = [None] * info.world
+    dist.all_gather_object(rows, row.tolist())
+    gathered = [None] * info.world
+    dist.all_gather_object(gathered, got)
+    if info.rank == 0:
+        json.dump({"want": want, "ranks": gathered, "first_tok": first_tok, "cos_prefill": c0, "cos_step": c1, "heads_local": eng.Hq, "i_local": eng.I,
+                   "logits_width": int(eng.logits.shape[1]),
+                   "logits_equal": all(r == rows[0] for r in rows)}, open(out_path, "w"))
+    shutdown()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -130,3 +130,31 @@ def test_batched_engine_matches_single_stream(model, dev, B):
         got = eng.tokens(b)
         same = (got == want[b]).long().cumprod(0).sum().item()
         assert same >= 6, (b, got.tolist(), want[b].tolist())
+
+
+@pytest.mark.timeout(300)
+def test_tensor_parallel_engine_two_ranks(tmp_path):
+    """Sharded serving engine on real kernels: two processes (gloo, both on GPU 0) must
+    agree with each other exactly and with the unsharded engine up to bf16 reduction order."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "tp_engine.json")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(here, "_tp_engine_worker.py"), out]
+    print("launching 2-rank TP engine worker", flush=True)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    got = json.load(open(out))
+    assert got["heads_local"] == 2 and got["i_local"] == 704 and got["logits_width"] == 515
+    assert got["ranks"][0] == got["ranks"][1]           # the ranks agree token for token
+    assert got["logits_equal"]
+    # same first token, and the residual stream after one more step of layers agrees with
+    # the unsharded engine up to the bf16 rounding of the partial sums (a wrong shard,
+    # position or cache row would put the cosine far below this)
+    for b, want in enumerate(got["want"]):
+        assert got["first_tok"][b] == want[0] == got["ranks"][0][b][0]
+        assert got["cos_prefill"][b] > 0.999 and got["cos_step"][b] > 0.995, got
