@@ -29,8 +29,8 @@ import torch
 from ..eval.reports import markdown_table, write_json
 from ..eval.timers import StageTimer, gpu_memory_mb
 from ..pipeline.dataset import DEFAULT_QUESTION, InstructionDataset
-from .stages import (STAGE_KEYS, EventGPTStages, VideoLlavaStages, _use_engine,
-                     compute_aligned_acceptance_rate)
+from .stages import (STAGE_KEYS, EventGPTStages, VideoLlavaStages, _use_engine,  # noqa: F401
+                     compute_aligned_acceptance_rate, frames_to_grid)
 
 
 # ------------------------------------------------------------------ acceptance
@@ -124,26 +124,6 @@ def decode_token_times(model, embeds: torch.Tensor, max_new_tokens: int, eos: in
             "per_token_ms_mean": float(gaps.mean()) if gaps.size else 0.0,
             "per_token_ms_p50": float(np.median(gaps)) if gaps.size else 0.0,
             "per_token_ms_max": float(gaps.max()) if gaps.size else 0.0}
-
-
-def frames_to_grid(frames: Sequence, rows: int = 2, cols: int = 4) -> np.ndarray:
-    """Tile ``rows*cols`` frames into one image (how a single-image verifier such as
-    LLaVA-1.5 is fed a clip; benchmark_inference.py:213-251).  Missing frames repeat
-    the last one; all tiles take the first frame's size."""
-    arrs = [np.asarray(f) for f in frames][: rows * cols]
-    if not arrs:
-        raise ValueError("no frames")
-    while len(arrs) < rows * cols:
-        arrs.append(arrs[-1])
-    h, w = arrs[0].shape[:2]
-    canvas = np.zeros((rows * h, cols * w) + arrs[0].shape[2:], dtype=arrs[0].dtype)
-    for i, a in enumerate(arrs):
-        if a.shape[:2] != (h, w):
-            from PIL import Image
-            a = np.asarray(Image.fromarray(a).resize((w, h)))
-        r, c = divmod(i, cols)
-        canvas[r * h:(r + 1) * h, c * w:(c + 1) * w] = a
-    return canvas
 
 
 # ------------------------------------------------------------------ the runner

@@ -79,7 +79,7 @@ def compute_aligned_acceptance_rate(draft_tokens: Sequence[int], target_tokens: 
 
 # ---------------------------------------------------------------- LLM stages
 def _use_engine(model, embeds) -> bool:
-    return embeds.is_cuda and embeds.dtype == torch.bfloat16
+    return embeds.is_cuda and embeds.dtype == torch.bfloat16 and not isinstance(model, _ModulePath)
 
 
 @torch.no_grad()
@@ -150,9 +150,33 @@ class EventGPTStages:
                                "inputs_embeds": list(emb.shape)})
 
 
+def frames_to_grid(frames: Sequence, rows: int = 2, cols: int = 4) -> np.ndarray:
+    """Tile ``rows*cols`` frames into one image: how a single-image verifier (LLaVA-1.5)
+    is fed a clip (benchmark_inference.py:213-251).  Missing frames repeat the last one;
+    all tiles take the first frame's size."""
+    arrs = [np.asarray(f) for f in frames][: rows * cols]
+    if not arrs:
+        raise ValueError("no frames")
+    while len(arrs) < rows * cols:
+        arrs.append(arrs[-1])
+    h, w = arrs[0].shape[:2]
+    canvas = np.zeros((rows * h, cols * w) + arrs[0].shape[2:], dtype=arrs[0].dtype)
+    for i, a in enumerate(arrs):
+        if a.shape[:2] != (h, w):
+            from PIL import Image
+            a = np.asarray(Image.fromarray(a).resize((w, h)))
+        r, c = divmod(i, cols)
+        canvas[r * h:(r + 1) * h, c * w:(c + 1) * w] = a
+    return canvas
+
+
 class VideoLlavaStages:
-    def __init__(self, model, processor, max_new_tokens: int = 50):
-        self.m, self.proc, self.max_new = model, processor, max_new_tokens
+    """Verifier pipeline.  ``grid=(rows, cols)`` tiles the sampled frames into ONE image
+    and runs the same model on it (the LLaVA-1.5 way of seeing a clip: one image's worth
+    of visual tokens instead of one per frame)."""
+
+    def __init__(self, model, processor, max_new_tokens: int = 50, grid: Optional[Sequence[int]] = None):
+        self.m, self.proc, self.max_new, self.grid = model, processor, max_new_tokens, grid
 
     def run(self, ds: InstructionDataset, sample: Dict, query: str) -> Optional[Dict]:
         m = self.m
@@ -163,6 +187,8 @@ class VideoLlavaStages:
             if not frames:
                 return None
         with timer.stage("stage2_time", host=True):
+            if self.grid:
+                frames = [frames_to_grid(frames, *self.grid)]
             inp = self.proc(VIDEO_PROMPT.format(query=query), frames, device=m.device, dtype=m.dtype)
             ids = inp["input_ids"].to(m.device)
             px = inp["pixel_values_videos"]
@@ -189,6 +215,60 @@ def _finish(timer: StageTimer, toks: List[int], prefill_len: int, kv_mb: float, 
     r["output"] = tokenizer.decode(toks, skip_special_tokens=True).strip() if tokenizer is not None else ""
     r["shapes"] = shapes
     return r
+
+
+# ------------------------------------------------- instrumentation equivalence
+@torch.no_grad()
+def verify_decoupling(model, processor, frames: Sequence, query: str, max_new_tokens: int = 16) -> Dict:
+    """The verifier's monolithic ``generate`` timed from the outside with forward hooks
+    vs the explicit staged pipeline: both must emit the same tokens, and the hook-side
+    stage times must add up to the monolithic wall time (the check the reference runs
+    before trusting staged numbers, verify_videollava_decoupling.py:87-340).  Uses the
+    module path on both sides so the hooks see every forward."""
+    from ..eval.timers import PrefillDecodeHooks, VisionTimingHooks
+    inp = processor(VIDEO_PROMPT.format(query=query), frames, device=model.device, dtype=model.dtype)
+    ids, px = inp["input_ids"].to(model.device), inp["pixel_values_videos"]
+    vis, pd = VisionTimingHooks(model), PrefillDecodeHooks(model)
+    # the vision hook sits on the tower module itself
+    tower = model.video_tower
+    vis.hooks.append(tower.register_forward_pre_hook(lambda m, i: setattr(vis, "_a", vis._span())))
+    vis.hooks.append(tower.register_forward_hook(lambda m, i, o: setattr(vis, "_b", vis._span())))
+    pd.register_hooks()
+    timer = StageTimer(model.device)
+    try:
+        with timer.stage("monolithic"):
+            mono = model.generate(ids, px, max_new_tokens=max_new_tokens, use_engine=False)[0].tolist()
+        pd.finalize_decode_time()
+        hooked = {"vision_s": vis.vision_time, "prefill_s": pd.prefill_time, "decode_s": pd.decode_time,
+                  "forwards": pd.forwards}
+    finally:
+        vis.unregister()
+        pd.unregister_hooks()
+    t2 = StageTimer(model.device)
+    with t2.stage("stage3_time"):
+        feats = model.get_video_features(px)
+        emb = model.merge_video_features(ids, feats)[0]
+    toks, _ = llm_prefill_decode(_ModulePath(model), emb, max_new_tokens, model.config.text_config.eos_token_id, t2)
+    staged = {k: v / 1e3 for k, v in t2.result().items()}
+    mono_s = timer.result()["monolithic"] / 1e3
+    n = min(len(mono), len(toks))
+    return {"identical_tokens": mono[:n] == toks[:n] and n > 0, "n_tokens": n, "monolithic_s": mono_s,
+            "hooked": hooked, "staged": staged,
+            "hook_coverage": (hooked["vision_s"] + hooked["prefill_s"] + hooked["decode_s"]) / mono_s if mono_s else 0.0}
+
+
+class _ModulePath:
+    """View of a model that makes ``llm_prefill_decode`` take the module path."""
+
+    def __init__(self, model):
+        self._m = model
+        self.language_model = getattr(model, "language_model", model)
+
+    def __getattr__(self, name):
+        return getattr(self._m, name)
+
+    def engine(self):
+        raise RuntimeError("module path requested")
 
 
 # ------------------------------------------------------------------ summaries
@@ -295,6 +375,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--compare_1vs8", action="store_true", help="drafter on 1 event frame vs verifier on 8 frames")
     p.add_argument("--from_npy", action="store_true", help="start stage 1 from the raw event stream")
     p.add_argument("--num_frames", type=int, default=5)
+    p.add_argument("--verify_decoupling", action="store_true",
+                   help="check hook-timed monolithic generate == staged pipeline on the first sample")
+    p.add_argument("--llava15_grid", action="store_true",
+                   help="also run the verifier on one 2x4 grid image of the frames (LLaVA-1.5 style)")
     p.add_argument("--speculative", action="store_true", help="report acceptance, c and theoretical SD speedup")
     p.add_argument("--gamma", type=int, default=4)
     p.add_argument("--use_token_adapter", action="store_true")
@@ -329,6 +413,8 @@ def main(argv=None) -> Dict:
                                           args.max_new_tokens)}
     if not args.eventgpt_only:
         runners["Video-LLaVA"] = VideoLlavaStages(vl, vproc, args.max_new_tokens)
+        if args.llava15_grid:
+            runners["LLaVA-1.5 (2x4 grid)"] = VideoLlavaStages(vl, vproc, args.max_new_tokens, grid=(2, 4))
     records: Dict[str, List[Dict]] = {k: [] for k in runners}
     for i, sample in enumerate(ds.samples):
         q = ds.question(sample) or DEFAULT_QUESTION
@@ -337,12 +423,23 @@ def main(argv=None) -> Dict:
             if rec is not None and i >= args.warmup:
                 rec["sample"] = i
                 records[name].append(rec)
+    decoupling = None
+    if args.verify_decoupling and not args.eventgpt_only and len(ds.samples):
+        src = ds.video_source(ds.samples[0])
+        fr = load_video_frames(src, vl.config.num_frames) if src else None
+        if fr:
+            decoupling = verify_decoupling(vl, vproc, fr, ds.question(ds.samples[0]) or DEFAULT_QUESTION,
+                                           min(args.max_new_tokens, 16))
+            print(f"[stages] decoupling check: identical tokens = {decoupling['identical_tokens']}, hooks cover "
+                  f"{100 * decoupling['hook_coverage']:.0f} % of the monolithic time")
     summaries = {k: summarize_5stage(v, k) for k, v in records.items() if v}
     result = {"timestamp": ts, "config": {"data": data_kind, "weights": args.random_init or "checkpoint",
                                           "num_frames": frames, "from_npy": args.from_npy,
                                           "max_new_tokens": args.max_new_tokens, "device": str(args.device)},
               "summaries": summaries, "memory": gpu_memory_mb(),
               "shapes": {k: v[0]["shapes"] for k, v in records.items() if v}, "samples": records}
+    if decoupling is not None:
+        result["decoupling_check"] = decoupling
     if "Video-LLaVA" in summaries and "EventGPT" in summaries:
         alpha = None
         if args.speculative:

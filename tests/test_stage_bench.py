@@ -43,3 +43,25 @@ def test_stage_benchmark_cpu(tmp_path):
     one = S.main(["--random_init", "tiny", "--device", "cpu", "--max_samples", "1", "--warmup", "0",
                   "--max_new_tokens", "4", "--compare_1vs8", "--eventgpt_only", "--output_dir", str(tmp_path)])
     assert one["shapes"]["EventGPT"]["pixel_values"][0] == 1 and "comparison" not in one
+
+
+def test_llava15_grid_variant(tmp_path):
+    """The single-image verifier variant sees one grid image: 1/T of the visual tokens."""
+    res = S.main(["--random_init", "tiny", "--device", "cpu", "--max_samples", "1", "--warmup", "0",
+                  "--max_new_tokens", "4", "--llava15_grid", "--output_dir", str(tmp_path)])
+    vl, grid = res["summaries"]["Video-LLaVA"], res["summaries"]["LLaVA-1.5 (2x4 grid)"]
+    sh_v, sh_g = res["shapes"]["Video-LLaVA"], res["shapes"]["LLaVA-1.5 (2x4 grid)"]
+    T = sh_v["pixel_values_videos"][1]
+    assert sh_g["pixel_values_videos"][1] == 1 and T > 1
+    assert sh_g["video_features"][1] * T == sh_v["video_features"][1]
+    assert grid["prefill_tokens_avg"] < vl["prefill_tokens_avg"]
+
+
+def test_decoupling_check(tmp_path):
+    res = S.main(["--random_init", "tiny", "--device", "cpu", "--max_samples", "1", "--warmup", "0",
+                  "--max_new_tokens", "6", "--verify_decoupling", "--output_dir", str(tmp_path)])
+    d = res["decoupling_check"]
+    assert d["identical_tokens"] and d["n_tokens"] >= 1
+    assert d["hooked"]["forwards"] == d["n_tokens"] or d["hooked"]["forwards"] == 6
+    assert d["hooked"]["vision_s"] > 0 and d["hooked"]["prefill_s"] > 0
+    assert 0.3 < d["hook_coverage"] <= 1.05
