@@ -121,16 +121,89 @@ def check_tokenizers(draft_tokenizer, target_tokenizer, probes: Sequence[str] = 
     return rep
 
 
+def analyze_benchmark_results(rows_or_path, tmap: Optional[Dict[int, int]] = None,
+                              positions: Sequence[int] = (1, 5, 10, 20)) -> Dict:
+    """Re-analyse a benchmark result file (list of ``{egpt_token_ids, llava_token_ids}``):
+    overall and per-sample acceptance, match rate at given positions, first-divergence
+    histogram — the analysis behind "the tokenizers agree, the *models* diverge"
+    (feasible/tokenizer_alignment/test_benchmark_alignment.py:12-148).  With ``tmap`` the
+    draft ids are translated first."""
+    import json
+    rows = rows_or_path
+    if isinstance(rows_or_path, str):
+        with open(rows_or_path) as f:
+            rows = json.load(f)
+        if isinstance(rows, dict):
+            rows = rows.get("results", rows.get("samples", []))
+    per, tot_d, tot_a = [], 0, 0
+    at_pos = {p: [0, 0] for p in positions}
+    first_div: Dict[int, int] = {}
+    for i, r in enumerate(rows):
+        d = list(r.get("egpt_token_ids") or r.get("egpt_tokens") or [])
+        t = list(r.get("llava_token_ids") or r.get("vl_tokens") or [])
+        if not d or not t:
+            continue
+        if tmap is not None:
+            d, _ = TokenizerAligner.translate_tokens(d, tmap)
+        n = min(len(d), len(t))
+        hits = [d[j] == t[j] for j in range(n)]
+        acc = sum(hits)
+        div = next((j for j, h in enumerate(hits) if not h), n)
+        first_div[div] = first_div.get(div, 0) + 1
+        for p_ in positions:
+            if p_ - 1 < n:
+                at_pos[p_][1] += 1
+                at_pos[p_][0] += int(hits[p_ - 1])
+        per.append({"sample_id": r.get("id", i), "draft_len": len(d), "target_len": len(t), "accepted": acc,
+                    "alpha": acc / len(d), "first_divergence": div})
+        tot_d, tot_a = tot_d + len(d), tot_a + acc
+    return {"n_samples": len(per), "total_draft_tokens": tot_d, "total_accepted": tot_a,
+            "alpha": tot_a / tot_d if tot_d else 0.0,
+            "match_at_position": {p_: (h / n if n else 0.0) for p_, (h, n) in at_pos.items()},
+            "first_divergence_hist": dict(sorted(first_div.items())),
+            "mean_first_divergence": (sum(k * v for k, v in first_div.items()) / max(sum(first_div.values()), 1)),
+            "samples": per}
+
+
+def matched_sampling_sweep(generate_pair, settings: Sequence[Tuple[float, float]] = ((0.0, 1.0), (0.3, 1.0), (0.6, 1.0),
+                                                                                   (1.0, 0.9)),
+                           n_samples: int = 5) -> List[Dict]:
+    """Does matching the sampling parameters of drafter and verifier raise acceptance?
+    (test_matched_sampling.py:13-140).  ``generate_pair(i, temperature, top_p)`` returns
+    ``(draft_ids, target_ids)`` for sample ``i``; every setting is applied to BOTH models."""
+    out = []
+    for temp, top_p in settings:
+        rows = []
+        for i in range(n_samples):
+            d, t = generate_pair(i, temp, top_p)
+            rows.append({"egpt_token_ids": list(d), "llava_token_ids": list(t)})
+        rep = analyze_benchmark_results(rows)
+        out.append({"temperature": temp, "top_p": top_p, "alpha": rep["alpha"],
+                    "mean_first_divergence": rep["mean_first_divergence"], "n_samples": rep["n_samples"]})
+    return out
+
+
 def main(argv=None) -> Dict:
     import argparse
     import json
 
     from ..data.tokenizer import load_tokenizer
     p = argparse.ArgumentParser(description="Compare / align drafter and verifier tokenizers")
-    p.add_argument("--eventgpt_model_path", required=True)
-    p.add_argument("--videollava_model_path", required=True)
+    p.add_argument("--eventgpt_model_path", default=None)
+    p.add_argument("--videollava_model_path", default=None)
     p.add_argument("--save_map", default=None, help="write the id translation table (.pt)")
+    p.add_argument("--analyze", default=None, help="benchmark result JSON to re-analyse")
     args = p.parse_args(argv)
+    if args.analyze:
+        tmap = None
+        if args.eventgpt_model_path and args.videollava_model_path:
+            tmap = TokenizerAligner(load_tokenizer(args.eventgpt_model_path),
+                                    load_tokenizer(args.videollava_model_path)).create_translation_map()
+        rep = analyze_benchmark_results(args.analyze, tmap)
+        print(json.dumps({k: v for k, v in rep.items() if k != "samples"}, indent=2))
+        return rep
+    if not (args.eventgpt_model_path and args.videollava_model_path):
+        p.error("--eventgpt_model_path and --videollava_model_path are required")
     d, t = load_tokenizer(args.eventgpt_model_path), load_tokenizer(args.videollava_model_path)
     rep = check_tokenizers(d, t)
     print(json.dumps(rep, indent=2, default=str))

@@ -242,3 +242,30 @@ def test_token_alignment_driver(tmp_path):
         res = R.main(["--mode", "evaluate", "--strategy", strat, *common])
         assert "aligned" in res and "baseline" in res, strat
     assert "gamma_5" in res["gamma_sweep"] if strat == "eagle_fusion" else True
+
+
+def test_benchmark_result_analysis_and_sampling_sweep(tmp_path):
+    from eventgpt_amd.align import tokenizers as TK
+    rows = [{"id": "a", "egpt_token_ids": [1, 2, 3, 4, 5], "llava_token_ids": [1, 2, 9, 4]},      # diverges at 2
+            {"id": "b", "egpt_token_ids": [7, 8], "llava_token_ids": [7, 8, 9]},                   # never within overlap
+            {"id": "c", "egpt_token_ids": [], "llava_token_ids": [1]}]                              # skipped
+    p = tmp_path / "bench.json"
+    p.write_text(json.dumps(rows))
+    rep = TK.analyze_benchmark_results(str(p), positions=(1, 3))
+    assert rep["n_samples"] == 2 and rep["total_draft_tokens"] == 7 and rep["total_accepted"] == 5
+    assert rep["alpha"] == pytest.approx(5 / 7)
+    assert rep["match_at_position"][1] == 1.0 and rep["match_at_position"][3] == 0.0
+    assert rep["first_divergence_hist"] == {2: 2}          # sample b "diverges" at the end of the overlap (2)
+    # translating the draft ids first (9 <- 3) repairs sample a
+    rep2 = TK.analyze_benchmark_results(rows, tmap={1: 1, 2: 2, 3: 9, 4: 4, 5: 5, 7: 7, 8: 8})
+    assert rep2["total_accepted"] == 6 and rep2["samples"][0]["first_divergence"] == 4
+    assert TK.main(["--analyze", str(p)])["n_samples"] == 2
+
+    # sweep: the "models" agree on a prefix that shrinks with temperature
+    def pair(i, temp, top_p):
+        keep = max(1, int(6 * (1 - temp)))
+        d = list(range(10, 16))
+        return d, d[:keep] + [99] * (6 - keep)
+    sw = TK.matched_sampling_sweep(pair, settings=((0.0, 1.0), (0.5, 1.0), (1.0, 0.9)), n_samples=3)
+    assert [round(r["alpha"], 3) for r in sw] == [1.0, 0.5, round(1 / 6, 3)]
+    assert sw[0]["mean_first_divergence"] == 6 and sw[2]["top_p"] == 0.9
