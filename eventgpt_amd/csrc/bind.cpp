@@ -313,15 +313,18 @@ Tensor argmax_rows(const Tensor& x) {
 // x [B,H] -> q_out [B,Hq*D], append K/V rows at pos[b] in caches [B,Hkv,Lmax,D]
 void decode_qkv(const Tensor& x, const Tensor& norm_w, const Tensor& w_qkv, const Tensor& q_out,
                 const Tensor& k_cache, const Tensor& v_cache, const Tensor& cos, const Tensor& sin,
-                const Tensor& pos, double eps, int64_t Hq, int64_t Hkv, int64_t D) {
+                const Tensor& pos, double eps, int64_t Hq, int64_t Hkv, int64_t D, bool one_seq) {
+  // one_seq: the rows of x are consecutive positions pos[0], pos[0]+1, ... of the single
+  // sequence whose cache slice [1,Hkv,Lmax,D] is passed (speculative verify); otherwise
+  // row b is sequence b at pos[b] (decode).
   check_bf16(x, "x"); check_bf16(norm_w, "norm_w"); check_bf16(w_qkv, "w_qkv");
   check_bf16(q_out, "q_out"); check_bf16(k_cache, "k_cache"); check_bf16(v_cache, "v_cache");
   check_f32(cos, "cos"); check_f32(sin, "sin"); check_i32(pos, "pos");
   const int64_t B = x.size(0), K = x.size(1);
   TORCH_CHECK(x.dim() == 2 && B <= evgpt::gemv_max_batch() && K % 8 == 0 && norm_w.numel() == K);
   TORCH_CHECK(w_qkv.size(0) == (Hq + 2 * Hkv) * D && w_qkv.size(1) == K, "decode_qkv: bad w_qkv");
-  TORCH_CHECK(D % 16 == 0 && q_out.numel() == B * Hq * D && pos.numel() == B);
-  TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(0) == B && k_cache.size(1) == Hkv &&
+  TORCH_CHECK(D % 16 == 0 && q_out.numel() == B * Hq * D && pos.numel() == (one_seq ? 1 : B));
+  TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(0) == (one_seq ? 1 : B) && k_cache.size(1) == Hkv &&
               k_cache.size(3) == D && v_cache.sizes() == k_cache.sizes());
   TORCH_CHECK(cos.size(-1) == D / 2 && cos.size(0) >= k_cache.size(2),
               "decode_qkv: rope table shorter than the cache");
@@ -329,7 +332,7 @@ void decode_qkv(const Tensor& x, const Tensor& norm_w, const Tensor& w_qkv, cons
   evgpt::launch_gemv_qkv_rope(bptr(w_qkv), bptr(x), bptr(norm_w), (float)eps, bptr_mut(q_out),
                               bptr_mut(k_cache), bptr_mut(v_cache), cos.data_ptr<float>(),
                               sin.data_ptr<float>(), pos.data_ptr<int>(), (int)B, (int)Hq, (int)Hkv,
-                              (int)D, (int)k_cache.size(2), (int)K, cur_stream());
+                              (int)D, (int)k_cache.size(2), (int)K, cur_stream(), one_seq ? 1 : 0);
 }
 
 void decode_attn(const Tensor& q, const Tensor& k_cache, const Tensor& v_cache, const Tensor& out,
@@ -600,6 +603,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("layernorm(Tensor x, Tensor w, Tensor? b, float eps) -> Tensor", &layernorm);
   m.def("linear(Tensor x, Tensor w, Tensor? bias, Tensor? res, int act, bool out_f32) -> Tensor", &linear);
   m.def("linear_partial(Tensor x, Tensor w) -> Tensor", &linear_partial);
+  m.def("gemv_max_batch() -> int", []() -> int64_t { return evgpt::gemv_max_batch(); });
   m.def("reduce_residual_norm(Tensor partial, Tensor? res, Tensor? norm_w, float eps, Tensor(a!)? out) -> (Tensor, Tensor)", &reduce_residual_norm);
   m.def("reduce_swiglu(Tensor partial) -> Tensor", &reduce_swiglu);
   m.def("reduce_rope_kv(Tensor partial, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos0, int B, int S, int Hq, int Hkv, int D) -> ()", &reduce_rope_kv);
@@ -609,7 +613,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("attention_cache(Tensor q, Tensor k_cache, Tensor v_cache, Tensor(a!) out, Tensor kv_len, float scale) -> ()", &attention_cache);
   m.def("st_pool(Tensor f, int n_temporal) -> Tensor", &st_pool);
   m.def("argmax_rows(Tensor x) -> Tensor", &argmax_rows);
-  m.def("decode_qkv(Tensor x, Tensor norm_w, Tensor w_qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos, float eps, int Hq, int Hkv, int D) -> ()", &decode_qkv);
+  m.def("decode_qkv(Tensor x, Tensor norm_w, Tensor w_qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos, float eps, int Hq, int Hkv, int D, bool one_seq=False) -> ()", &decode_qkv);
   m.def("decode_attn(Tensor q, Tensor k_cache, Tensor v_cache, Tensor(a!) out, Tensor(b!) part_o, Tensor(c!) part_ml, Tensor pos, int nsplit, float scale) -> ()", &decode_attn);
   m.def("decode_gemv_residual(Tensor w, Tensor xin, Tensor(a!) y) -> ()", &decode_gemv_residual);
   m.def("decode_gemv(Tensor w, Tensor xin, Tensor(a!) y, bool accumulate) -> ()", &decode_gemv);

@@ -18,7 +18,8 @@ void launch_gemv_swiglu(const bf16_t* W_gate_up, const bf16_t* x, bf16_t* y,
 void launch_gemv_qkv_rope(const bf16_t* W_qkv, const bf16_t* x, const bf16_t* norm_w, float eps,
                           bf16_t* q_out, bf16_t* k_cache, bf16_t* v_cache, const float* cos_tab,
                           const float* sin_tab, const int* pos, int B, int n_q_heads,
-                          int n_kv_heads, int head_dim, int l_max, int K, hipStream_t st);
+                          int n_kv_heads, int head_dim, int l_max, int K, hipStream_t st,
+                          int rows_one_seq = 0);
 void launch_gemv_logits(const bf16_t* W, const bf16_t* x, const bf16_t* norm_w, float eps,
                         float* logits, float* part_val, int* part_idx, int B, int N, int K,
                         hipStream_t st);

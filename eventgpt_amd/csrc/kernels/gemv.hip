@@ -49,7 +49,8 @@ struct GemvParams {
   bf16_t* v_cache;
   const float* cos_tab;  // [max_pos][D/2]
   const float* sin_tab;
-  const int* pos;        // [B] device-resident positions
+  const int* pos;        // [B] device-resident positions, or [1] with rows_one_seq
+  int rows_one_seq;      // 1: the B rows are positions pos[0]+b of ONE sequence (cache slot 0)
   int n_q_heads, n_kv_heads, head_dim, l_max;
   // E_LOGITS
   float* logits;         // [B][N] or null
@@ -333,16 +334,20 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
           // the position is a device counter: clamp it into the cache so a
           // sequence that ran past its capacity overwrites the last slot
           // instead of writing outside the allocation
-          const int pos_raw = p.pos[b];
+          const int pos_raw = p.rows_one_seq ? p.pos[0] + b : p.pos[b];
           const int pos = pos_raw < 0 ? 0 : (pos_raw >= p.l_max ? p.l_max - 1 : pos_raw);
+          const int slot = p.rows_one_seq ? 0 : b;   // cache slot of this row's sequence
+          // a row past the cache of a multi-row pass is dropped, never wrapped onto a live slot
+          const bool kv_ok = !p.rows_one_seq || (pos_raw >= 0 && pos_raw < p.l_max);
           if (row[0] < q_rows + k_rows) {
             const int h_all = row[0] / hd, j = row[0] % hd;  // j < hh
             bf16_t* dst;
             if (h_all < p.n_q_heads) {
               dst = p.q_out + static_cast<size_t>(b) * q_rows + h_all * hd;
             } else {
+              if (!kv_ok) continue;
               const int h = h_all - p.n_q_heads;
-              dst = p.k_cache + ((static_cast<size_t>(b) * p.n_kv_heads + h) * p.l_max + pos) * hd;
+              dst = p.k_cache + ((static_cast<size_t>(slot) * p.n_kv_heads + h) * p.l_max + pos) * hd;
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -354,9 +359,10 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
               dst[j + i + hh] = f32_to_bf16(x2 * c + x1 * s);
             }
           } else {
+            if (!kv_ok) continue;
             const int vr = row[0] - q_rows - k_rows;
             const int h = vr / hd, j = vr % hd;
-            bf16_t* dst = p.v_cache + ((static_cast<size_t>(b) * p.n_kv_heads + h) * p.l_max + pos) * hd;
+            bf16_t* dst = p.v_cache + ((static_cast<size_t>(slot) * p.n_kv_heads + h) * p.l_max + pos) * hd;
 #pragma unroll
             for (int r = 0; r < R; ++r) dst[j + r] = f32_to_bf16(acc[r][b]);
           }
@@ -470,8 +476,10 @@ void launch_gemv_swiglu(const bf16_t* W_gate_up, const bf16_t* x, bf16_t* y,
 void launch_gemv_qkv_rope(const bf16_t* W_qkv, const bf16_t* x, const bf16_t* norm_w, float eps,
                           bf16_t* q_out, bf16_t* k_cache, bf16_t* v_cache, const float* cos_tab,
                           const float* sin_tab, const int* pos, int B, int n_q_heads,
-                          int n_kv_heads, int head_dim, int l_max, int K, hipStream_t st) {
+                          int n_kv_heads, int head_dim, int l_max, int K, hipStream_t st,
+                          int rows_one_seq) {
   GemvParams p{};
+  p.rows_one_seq = rows_one_seq;
   p.W = W_qkv; p.x = x; p.norm_w = norm_w; p.eps = eps; p.K = K;
   p.N = (n_q_heads + 2 * n_kv_heads) * head_dim;
   p.q_out = q_out; p.k_cache = k_cache; p.v_cache = v_cache; p.cos_tab = cos_tab;

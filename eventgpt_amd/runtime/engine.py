@@ -191,13 +191,39 @@ class GenerationEngine:
             self._logits_and_commit(greedy=(select == "greedy"))
         return x[0] if return_hidden else None
 
+    # Up to gemv_rows rows of ONE sequence (short speculative verifies) run on the decode
+    # step's weight-streaming kernels: fused norm+QKV+RoPE+cache append, o_proj+residual,
+    # fused norm+gate/up+SwiGLU, down+residual: 4 launches + attention per layer.
+    gemv_rows = 3
+
+    def _gemv_rows_ok(self, rows: int) -> bool:
+        return 1 <= rows <= min(self.gemv_rows, int(self.raw.gemv_max_batch())) and self.tp_world == 1
+
+    def _forward_rows_gemv(self, embeds: torch.Tensor, batch: int, pos0: torch.Tensor) -> torch.Tensor:
+        raw = self.raw
+        S = embeds.shape[0]
+        x = embeds.to(torch.bfloat16).reshape(S, self.H).clone()      # residual stream, updated in place
+        kv_len = pos0 + S
+        q = torch.empty(1, S, self.Hq, self.D, dtype=torch.bfloat16, device=self.device)
+        o = torch.empty_like(q)
+        h = torch.empty(S, self.I, dtype=torch.bfloat16, device=self.device)
+        for l in self.layers:
+            kc, vc = l.k_cache[batch:batch + 1], l.v_cache[batch:batch + 1]
+            raw.decode_qkv(x, l.norm1, l.w_qkv, q, kc, vc, self.cos, self.sin, pos0, self.eps,
+                           self.Hq, self.Hkv, self.D, True)
+            raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
+            raw.decode_gemv_residual(l.w_o, o.view(S, self.Hq * self.D), x)
+            raw.decode_mlp_up(l.w_gate_up, x, l.norm2, self.eps, h)
+            raw.decode_gemv_residual(l.w_down, h, x)
+        return x.view(1, S, self.H)
+
     # Row counts up to this take the few-row path: projections stop at their fp32
     # split-K slabs and the op that follows (RoPE + cache append, residual + next
     # RMSNorm, SwiGLU) is done by the kernel that sums the slabs.
     fused_rows = 32
 
     def _few_rows_ok(self, rows: int) -> bool:
-        return (4 < rows <= self.fused_rows and self.tp_world == 1 and self.H % 64 == 0
+        return (3 < rows <= self.fused_rows and self.tp_world == 1 and self.H % 64 == 0
                 and self.I % 64 == 0 and (self.Hq * self.D) % 64 == 0)
 
     def _forward_rows_fused(self, embeds: torch.Tensor, batch: int, pos0: torch.Tensor) -> torch.Tensor:
@@ -228,6 +254,8 @@ class GenerationEngine:
         final norm.  Does not touch the position counters."""
         raw = self.raw
         S = embeds.shape[0]
+        if self._gemv_rows_ok(S):
+            return self._forward_rows_gemv(embeds, batch, pos0)
         if self._few_rows_ok(S):
             return self._forward_rows_fused(embeds, batch, pos0)
         x = embeds.to(torch.bfloat16).contiguous().view(1, S, self.H)

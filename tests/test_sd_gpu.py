@@ -180,3 +180,37 @@ def test_linear_argmax_partials(dev):
     got = pi.gather(1, pv.argmax(1, keepdim=True))[:, 0].long()
     ref = hip.linear(x, w).float()
     assert torch.equal(ref.gather(1, got[:, None]), ref.max(1, keepdim=True).values)
+
+
+@pytest.mark.parametrize("G", [1, 2])
+def test_short_verify_on_decode_kernels(target, dev, G):
+    """Verifies of up to 3 rows run on the decode step's fused weight-streaming kernels
+    (one-sequence QKV epilogue); they must leave the same cache rows, hidden states and
+    accept decisions as the generic row path."""
+    from eventgpt_amd.runtime.engine import GenerationEngine
+    emb = _emb(dev, 29, seed=4)
+    fast = GenerationEngine(target, max_len=256, max_new_tokens=64, use_graph=False)
+    slow = GenerationEngine(target, max_len=256, max_new_tokens=64, use_graph=False)
+    slow.gemv_rows = 0                                   # force the generic path
+    assert fast._gemv_rows_ok(G + 1) and not slow._gemv_rows_ok(G + 1)
+    greedy = fast.generate(emb, 12, eos_token_id=-1)
+    for e in (fast, slow):
+        e.eos = -1
+        e.reset()
+        e.prefill(emb, select="greedy")
+    for it in range(3):
+        n = int(fast.step[0].item())
+        draft = greedy[n:n + G].to(torch.int32).clone()
+        if it == 1:
+            draft[-1] = (draft[-1] + 1) % 128            # reject the last draft token
+        hf = fast.verify(draft, G, return_hidden=True)
+        hs = slow.verify(draft, G, return_hidden=True)
+        assert torch.equal(fast.sd_result[:3], slow.sd_result[:3]), (it, fast.sd_result, slow.sd_result)
+        assert torch.equal(fast.pos, slow.pos)
+        assert torch.allclose(hf.float(), hs.float(), atol=3e-2, rtol=3e-2)
+        p = int(fast.pos[0].item())
+        for lf, ls in zip(fast.layers, slow.layers):
+            assert torch.allclose(lf.k_cache[0, :, :p].float(), ls.k_cache[0, :, :p].float(), atol=3e-2, rtol=3e-2)
+            assert torch.allclose(lf.v_cache[0, :, :p].float(), ls.v_cache[0, :, :p].float(), atol=3e-2, rtol=3e-2)
+    n = int(fast.step[0].item())
+    assert torch.equal(fast.out_tokens[0, :n].long(), greedy[:n])
