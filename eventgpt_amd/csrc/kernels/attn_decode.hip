@@ -131,16 +131,21 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __r
   // issue every load before the first use: the kernel is a handful of dependent
   // L2 round trips, so they must overlap
   float ms[MAXS], ls[MAXS], os[MAXS];
+  // (splits past nsplit re-read split 0 and are masked afterwards: a select between a
+  // load and a constant would put every load behind its own branch)
 #pragma unroll
   for (int s = 0; s < MAXS; ++s) {
-    const bool ok = s < nsplit;
-    ms[s] = ok ? part_ml[(base + s) * 2] : -INFINITY;
-    ls[s] = ok ? part_ml[(base + s) * 2 + 1] : 0.f;
-    os[s] = ok ? part_o[(base + s) * D + d] : 0.f;
+    const size_t slot = base + (s < nsplit ? s : 0);
+    ms[s] = part_ml[slot * 2];
+    ls[s] = part_ml[slot * 2 + 1];
+    os[s] = part_o[slot * D + d];
   }
   float mm = -INFINITY;
 #pragma unroll
-  for (int s = 0; s < MAXS; ++s) mm = fmaxf(mm, ms[s]);
+  for (int s = 0; s < MAXS; ++s) {
+    ms[s] = s < nsplit ? ms[s] : -INFINITY;
+    mm = fmaxf(mm, ms[s]);
+  }
   float ll = 0.f, oo = 0.f;
 #pragma unroll
   for (int s = 0; s < MAXS; ++s) {

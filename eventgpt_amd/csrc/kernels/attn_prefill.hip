@@ -237,18 +237,30 @@ template <int D>
 __global__ __launch_bounds__(D) void attn_split_combine_kernel(AttnParams p) {
   const int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
   const long long base = (static_cast<long long>(b) * p.Hq + h) * p.nsplit;
+  // Every load is issued before the first use and none sits behind a branch: the
+  // kernel is a handful of L2 round trips and they must overlap.  Splits past
+  // nsplit re-read split 0 and are masked afterwards.
+  constexpr int MAXS = 16;
+  float ms[MAXS], ls[MAXS], os[MAXS];
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    const long long slot = (base + (s < p.nsplit ? s : 0)) * p.Sq + qi;
+    ms[s] = p.part_ml[slot * 2];
+    ls[s] = p.part_ml[slot * 2 + 1];
+    os[s] = p.part_o[slot * D + d];
+  }
   float mx = -INFINITY;
-  for (int s = 0; s < p.nsplit; ++s) mx = fmaxf(mx, p.part_ml[((base + s) * p.Sq + qi) * 2]);
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    ms[s] = s < p.nsplit ? ms[s] : -INFINITY;
+    mx = fmaxf(mx, ms[s]);
+  }
   float acc = 0.f, l = 0.f;
-  if (mx != -INFINITY) {
-    for (int s = 0; s < p.nsplit; ++s) {
-      const long long slot = (base + s) * p.Sq + qi;
-      const float ms = p.part_ml[slot * 2];
-      if (ms == -INFINITY) continue;
-      const float w = exp2f(ms - mx);
-      l += w * p.part_ml[slot * 2 + 1];
-      acc += w * p.part_o[slot * D + d];
-    }
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    const float w = (ms[s] == -INFINITY) ? 0.f : exp2f(ms[s] - mx);
+    l += w * ls[s];
+    acc += w * os[s];
   }
   bf16_t* op = p.o + b * p.o_sb + static_cast<long long>(qi) * p.o_ss + h * p.o_sh;
   op[d] = f32_to_bf16(l > 0.f ? acc / l : 0.f);

@@ -18,21 +18,50 @@ namespace evgpt {
 
 // 8 consecutive columns starting at element e0 of the [M][N] slab, summed over
 // the slabs in slab order and rounded to bf16 (returned as 4 packed pairs).
+// NS > 0: the slab count is a compile-time constant, so all 2*NS loads are issued
+// before the first add (these kernels are a few L2 round trips; a runtime-bound
+// loop would take them one after the other).  NS == 0: any count.
+template <int NS>
 __device__ __forceinline__ u32x4_t sum8_bf16(const float* __restrict__ partial, size_t slab,
                                              int nslab, size_t e0) {
   f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < nslab; ++s) {
-    const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(partial + s * slab + e0);
-    const f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(partial + s * slab + e0 + 4);
-    a[0] += t0[0]; a[1] += t0[1]; a[2] += t0[2]; a[3] += t0[3];
-    b[0] += t1[0]; b[1] += t1[1]; b[2] += t1[2]; b[3] += t1[3];
+  if constexpr (NS > 0) {
+    f32x4_t t0[NS], t1[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      t0[s] = *reinterpret_cast<const f32x4_t*>(partial + s * slab + e0);
+      t1[s] = *reinterpret_cast<const f32x4_t*>(partial + s * slab + e0 + 4);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      a[0] += t0[s][0]; a[1] += t0[s][1]; a[2] += t0[s][2]; a[3] += t0[s][3];
+      b[0] += t1[s][0]; b[1] += t1[s][1]; b[2] += t1[s][2]; b[3] += t1[s][3];
+    }
+  } else {
+    for (int s = 0; s < nslab; ++s) {
+      const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(partial + s * slab + e0);
+      const f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(partial + s * slab + e0 + 4);
+      a[0] += t0[0]; a[1] += t0[1]; a[2] += t0[2]; a[3] += t0[3];
+      b[0] += t1[0]; b[1] += t1[1]; b[2] += t1[2]; b[3] += t1[3];
+    }
   }
   return u32x4_t{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
                  pack_bf16x2(b[2], b[3])};
 }
 
+// expands `LAUNCH(NS)` with NS = nslab when it is 1, 2, 4 or 8, else NS = 0 (runtime count)
+#define EVGPT_NSLAB_SWITCH(nslab, LAUNCH) \
+  switch (nslab) {                        \
+    case 1: LAUNCH(1); break;             \
+    case 2: LAUNCH(2); break;             \
+    case 4: LAUNCH(4); break;             \
+    case 8: LAUNCH(8); break;             \
+    default: LAUNCH(0); break;            \
+  }
+
 // x_out[m] = bf16(sum) + res[m];  xn_out[m] = RMSNorm(x_out[m]) * norm_w  (if norm_w)
 // One block per row.  x_out may alias res.
+template <int NS>
 __global__ __launch_bounds__(256) void reduce_residual_norm_kernel(
     const float* __restrict__ partial, int nslab, int M, int N, const bf16_t* res, bf16_t* x_out,
     const bf16_t* __restrict__ norm_w, bf16_t* __restrict__ xn_out, float eps) {
@@ -42,7 +71,7 @@ __global__ __launch_bounds__(256) void reduce_residual_norm_kernel(
   const int nchunk = N >> 3;
   float ss = 0.f;
   for (int c = threadIdx.x; c < nchunk; c += 256) {
-    u32x4_t v = sum8_bf16(partial, slab, nslab, base + c * 8);
+    u32x4_t v = sum8_bf16<NS>(partial, slab, nslab, base + c * 8);
     if (res) {
       const u32x4_t r = load16(res + base + c * 8);
 #pragma unroll
@@ -74,6 +103,7 @@ __global__ __launch_bounds__(256) void reduce_residual_norm_kernel(
 }
 
 // partial [nslab][M][2I] laid out [gate | up] -> out [M][I]
+template <int NS>
 __global__ __launch_bounds__(256) void reduce_swiglu_kernel(const float* __restrict__ partial,
                                                             int nslab, long long M, int I,
                                                             bf16_t* __restrict__ out) {
@@ -83,8 +113,8 @@ __global__ __launch_bounds__(256) void reduce_swiglu_kernel(const float* __restr
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
     const long long m = i / cpr;
     const int c = static_cast<int>(i % cpr);
-    const u32x4_t g = sum8_bf16(partial, slab, nslab, static_cast<size_t>(m) * 2 * I + c * 8);
-    const u32x4_t u = sum8_bf16(partial, slab, nslab, static_cast<size_t>(m) * 2 * I + I + c * 8);
+    const u32x4_t g = sum8_bf16<NS>(partial, slab, nslab, static_cast<size_t>(m) * 2 * I + c * 8);
+    const u32x4_t u = sum8_bf16<NS>(partial, slab, nslab, static_cast<size_t>(m) * 2 * I + I + c * 8);
     u32x4_t o;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -95,6 +125,7 @@ __global__ __launch_bounds__(256) void reduce_swiglu_kernel(const float* __restr
 
 // partial [nslab][B*S][(Hq+2Hkv)*D] -> q_out [B][S][Hq*D], k/v cache rows at pos0[b]+s.
 // Thread = one 8-wide chunk of the first half of a head and its rotate-half partner.
+template <int NS>
 __global__ __launch_bounds__(256) void reduce_rope_kv_kernel(
     const float* __restrict__ partial, int nslab, bf16_t* __restrict__ q_out,
     bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, const float* __restrict__ cos_tab,
@@ -116,8 +147,8 @@ __global__ __launch_bounds__(256) void reduce_rope_kv_kernel(
     pos = pos < 0 ? 0 : (pos >= l_max ? l_max - 1 : pos);
     if (h >= Hq && !in_cache) continue;
     const size_t src = (static_cast<size_t>(b) * S + s) * heads * D + h * D + c * 8;
-    const u32x4_t a = sum8_bf16(partial, slab, nslab, src);
-    const u32x4_t bb = sum8_bf16(partial, slab, nslab, src + hh);
+    const u32x4_t a = sum8_bf16<NS>(partial, slab, nslab, src);
+    const u32x4_t bb = sum8_bf16<NS>(partial, slab, nslab, src + hh);
     bf16_t* dst;
     if (h < Hq) {
       dst = q_out + (static_cast<size_t>(b) * S + s) * Hq * D + h * D;
@@ -147,8 +178,11 @@ __global__ __launch_bounds__(256) void reduce_rope_kv_kernel(
 void launch_reduce_residual_norm(const float* partial, int nslab, int M, int N, const bf16_t* res,
                                  bf16_t* x_out, const bf16_t* norm_w, bf16_t* xn_out, float eps,
                                  hipStream_t st) {
-  hipLaunchKernelGGL(reduce_residual_norm_kernel, dim3(M), dim3(256), 0, st, partial, nslab, M, N,
-                     res, x_out, norm_w, xn_out, eps);
+#define L_(NS)                                                                                   \
+  hipLaunchKernelGGL(reduce_residual_norm_kernel<NS>, dim3(M), dim3(256), 0, st, partial, nslab, M, \
+                     N, res, x_out, norm_w, xn_out, eps)
+  EVGPT_NSLAB_SWITCH(nslab, L_)
+#undef L_
 }
 
 void launch_reduce_swiglu(const float* partial, int nslab, long long M, int I, bf16_t* out,
@@ -157,8 +191,10 @@ void launch_reduce_swiglu(const float* partial, int nslab, long long M, int I, b
   int blocks = static_cast<int>((work + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(reduce_swiglu_kernel, dim3(blocks), dim3(256), 0, st, partial, nslab, M, I,
-                     out);
+#define L_(NS) \
+  hipLaunchKernelGGL(reduce_swiglu_kernel<NS>, dim3(blocks), dim3(256), 0, st, partial, nslab, M, I, out)
+  EVGPT_NSLAB_SWITCH(nslab, L_)
+#undef L_
 }
 
 void launch_reduce_rope_kv(const float* partial, int nslab, bf16_t* q_out, bf16_t* k_cache,
@@ -169,8 +205,11 @@ void launch_reduce_rope_kv(const float* partial, int nslab, bf16_t* q_out, bf16_
   int blocks = static_cast<int>((work + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(reduce_rope_kv_kernel, dim3(blocks, B), dim3(256), 0, st, partial, nslab,
-                     q_out, k_cache, v_cache, cos_tab, sin_tab, pos0, S, Hq, Hkv, D, l_max);
+#define L_(NS)                                                                                  \
+  hipLaunchKernelGGL(reduce_rope_kv_kernel<NS>, dim3(blocks, B), dim3(256), 0, st, partial, nslab, \
+                     q_out, k_cache, v_cache, cos_tab, sin_tab, pos0, S, Hq, Hkv, D, l_max)
+  EVGPT_NSLAB_SWITCH(nslab, L_)
+#undef L_
 }
 
 }  // namespace evgpt
