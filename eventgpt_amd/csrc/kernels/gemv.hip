@@ -208,6 +208,15 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
     for (int b = 0; b < B; ++b) { best_val[b] = -INFINITY; best_idx[b] = 0; }
   }
 
+  // Epilogue operands that do not depend on the dot products are requested early, so
+  // the tail of a block is one memory round trip (the store), not a chain of them:
+  // positions here, the residual rows at the top of each unit.
+  int pos_in[B];
+  if constexpr (E == E_QKV_ROPE) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) pos_in[b] = p.rows_one_seq ? p.pos[0] + b : p.pos[b];
+  }
+
   // block-uniform trip count: the partial-sum exchange below contains a barrier
   for (int ub = blockIdx.x; ub < n_ub; ub += gridDim.x) {
     const int u = ub * UPB + ub_slot;
@@ -225,6 +234,32 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
+    bf16_t res_in[R][B];
+    if constexpr (E == E_RESIDUAL) {
+      if (lane == 0 && ks == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int b = 0; b < B; ++b)
+            res_in[r][b] = row[r] < p.N ? p.res[static_cast<size_t>(b) * p.N + row[r]] : bf16_t(0);
+      }
+    }
+
+    float cs_in[2][B], sn_in[2][B];
+    if constexpr (E == E_QKV_ROPE) {
+      if (lane == 0 && ks == 0 && row[0] < (p.n_q_heads + p.n_kv_heads) * p.head_dim) {
+        const int hh = p.head_dim >> 1, j = row[0] % p.head_dim;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          const int pc = pos_in[b] < 0 ? 0 : (pos_in[b] >= p.l_max ? p.l_max - 1 : pos_in[b]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            cs_in[i][b] = p.cos_tab[static_cast<size_t>(pc) * hh + j + i];
+            sn_in[i][b] = p.sin_tab[static_cast<size_t>(pc) * hh + j + i];
+          }
+        }
+      }
+    }
 
     auto consume = [&](const u32x4_t (&wv)[R], int c) {
 #pragma unroll
@@ -314,7 +349,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
               float v = acc[r][b];
               if (p.bias) v += bf16_to_f32(p.bias[row[r]]);
               v = apply_act(v, p.act);
-              v = bf16_to_f32(f32_to_bf16(v)) + bf16_to_f32(p.res[o]);
+              v = bf16_to_f32(f32_to_bf16(v)) + bf16_to_f32(res_in[r][b]);
               p.y[o] = f32_to_bf16(v);
             }
           }
@@ -334,7 +369,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
           // the position is a device counter: clamp it into the cache so a
           // sequence that ran past its capacity overwrites the last slot
           // instead of writing outside the allocation
-          const int pos_raw = p.rows_one_seq ? p.pos[0] + b : p.pos[b];
+          const int pos_raw = pos_in[b];
           const int pos = pos_raw < 0 ? 0 : (pos_raw >= p.l_max ? p.l_max - 1 : pos_raw);
           const int slot = p.rows_one_seq ? 0 : b;   // cache slot of this row's sequence
           // a row past the cache of a multi-row pass is dropped, never wrapped onto a live slot
@@ -351,8 +386,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              const float c = p.cos_tab[static_cast<size_t>(pos) * hh + j + i];
-              const float s = p.sin_tab[static_cast<size_t>(pos) * hh + j + i];
+              const float c = cs_in[i][b], s = sn_in[i][b];
               const float x1 = bf16_to_f32(f32_to_bf16(acc[i][b]));
               const float x2 = bf16_to_f32(f32_to_bf16(acc[2 + i][b]));
               dst[j + i] = f32_to_bf16(x1 * c - x2 * s);
