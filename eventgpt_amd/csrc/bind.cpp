@@ -194,6 +194,31 @@ void reduce_rope_kv(const Tensor& partial, const Tensor& q_out, const Tensor& k_
                                (int)Hkv, (int)D, (int)k_cache.size(2), cur_stream());
 }
 
+// (cos [rows], mse [rows]) of two equally shaped tensors whose last dim is the row
+std::tuple<Tensor, Tensor> row_metrics(const Tensor& a, const Tensor& b, double eps) {
+  TORCH_CHECK(a.is_cuda() && b.is_cuda() && a.is_contiguous() && b.is_contiguous() &&
+              a.sizes() == b.sizes() && a.scalar_type() == b.scalar_type(),
+              "row_metrics: two contiguous GPU tensors of one shape and dtype");
+  const int64_t H = a.size(-1), rows = H ? a.numel() / H : 0;
+  auto out_sizes = a.sizes().vec();
+  out_sizes.pop_back();
+  Tensor c = at::empty(out_sizes, a.options().dtype(at::kFloat));
+  Tensor m = at::empty(out_sizes, a.options().dtype(at::kFloat));
+  if (rows == 0) return {c, m};
+  if (a.scalar_type() == at::kFloat) {
+    TORCH_CHECK(H % 4 == 0, "row_metrics: row length must be a multiple of 4 (fp32)");
+    evgpt::launch_row_metrics_f32(a.data_ptr<float>(), b.data_ptr<float>(), c.data_ptr<float>(),
+                                  m.data_ptr<float>(), rows, (int)H, (float)eps, cur_stream());
+  } else if (a.scalar_type() == at::kBFloat16) {
+    TORCH_CHECK(H % 8 == 0, "row_metrics: row length must be a multiple of 8 (bf16)");
+    evgpt::launch_row_metrics_bf16(bptr(a), bptr(b), c.data_ptr<float>(), m.data_ptr<float>(), rows,
+                                   (int)H, (float)eps, cur_stream());
+  } else {
+    TORCH_CHECK(false, "row_metrics: float32 or bfloat16 only");
+  }
+  return {c, m};
+}
+
 Tensor swiglu(const Tensor& gate_up) {
   check_bf16(gate_up, "gate_up");
   const int64_t I2 = gate_up.size(-1);
@@ -613,6 +638,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("attention_cache(Tensor q, Tensor k_cache, Tensor v_cache, Tensor(a!) out, Tensor kv_len, float scale) -> ()", &attention_cache);
   m.def("st_pool(Tensor f, int n_temporal) -> Tensor", &st_pool);
   m.def("argmax_rows(Tensor x) -> Tensor", &argmax_rows);
+  m.def("row_metrics(Tensor a, Tensor b, float eps) -> (Tensor, Tensor)", &row_metrics);
   m.def("decode_qkv(Tensor x, Tensor norm_w, Tensor w_qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos, float eps, int Hq, int Hkv, int D, bool one_seq=False) -> ()", &decode_qkv);
   m.def("decode_attn(Tensor q, Tensor k_cache, Tensor v_cache, Tensor(a!) out, Tensor(b!) part_o, Tensor(c!) part_ml, Tensor pos, int nsplit, float scale) -> ()", &decode_attn);
   m.def("decode_gemv_residual(Tensor w, Tensor xin, Tensor(a!) y) -> ()", &decode_gemv_residual);

@@ -86,6 +86,10 @@ void launch_vit_embed_ln(const bf16_t* tok, const bf16_t* cls, const bf16_t* pos
 void launch_reduce_residual_norm(const float* partial, int nslab, int M, int N, const bf16_t* res,
                                  bf16_t* x_out, const bf16_t* norm_w, bf16_t* xn_out, float eps,
                                  hipStream_t st);
+void launch_row_metrics_f32(const float* a, const float* b, float* cos_out, float* mse_out,
+                            long long rows, int H, float eps, hipStream_t st);
+void launch_row_metrics_bf16(const bf16_t* a, const bf16_t* b, float* cos_out, float* mse_out,
+                             long long rows, int H, float eps, hipStream_t st);
 void launch_reduce_swiglu(const float* partial, int nslab, long long M, int I, bf16_t* out,
                           hipStream_t st);
 void launch_reduce_rope_kv(const float* partial, int nslab, bf16_t* q_out, bf16_t* k_cache,

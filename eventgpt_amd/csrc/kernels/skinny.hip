@@ -175,6 +175,64 @@ __global__ __launch_bounds__(256) void reduce_rope_kv_kernel(
   }
 }
 
+// ------------------------------------------------------------- row metrics
+// cos[r] = <a_r, b_r> / (|a_r| |b_r|),  mse[r] = mean_j (a_rj - b_rj)^2 for rows of
+// length H in ONE pass over both tensors (the evaluation metrics and the alignment
+// loss need both; separate normalise / multiply / reduce passes read the pair five
+// times).  One wave per row, 16-byte loads, fp32 accumulation.  T = float or bf16.
+template <typename T>
+__global__ __launch_bounds__(256) void row_metrics_kernel(const T* __restrict__ a,
+                                                          const T* __restrict__ b,
+                                                          float* __restrict__ cos_out,
+                                                          float* __restrict__ mse_out, long long rows,
+                                                          int H, float eps) {
+  const long long r = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  constexpr int EPV = 16 / sizeof(T);   // elements per 16-byte vector
+  const T* ar = a + r * H;
+  const T* br = b + r * H;
+  float dot = 0.f, na = 0.f, nb = 0.f, se = 0.f;
+  for (int c = lane; c < H / EPV; c += 64) {
+    float x[EPV], y[EPV];
+    if constexpr (sizeof(T) == 4) {
+      const f32x4_t va = *reinterpret_cast<const f32x4_t*>(ar + c * EPV);
+      const f32x4_t vb = *reinterpret_cast<const f32x4_t*>(br + c * EPV);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { x[i] = va[i]; y[i] = vb[i]; }
+    } else {
+      const u32x4_t va = load16(ar + c * EPV), vb = load16(br + c * EPV);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        x[2 * i] = bf16lo(va[i]); x[2 * i + 1] = bf16hi(va[i]);
+        y[2 * i] = bf16lo(vb[i]); y[2 * i + 1] = bf16hi(vb[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) {
+      dot += x[i] * y[i]; na += x[i] * x[i]; nb += y[i] * y[i];
+      const float d = x[i] - y[i];
+      se += d * d;
+    }
+  }
+  dot = wave_sum(dot); na = wave_sum(na); nb = wave_sum(nb); se = wave_sum(se);
+  if (lane == 0) {
+    cos_out[r] = dot / (fmaxf(sqrtf(na), eps) * fmaxf(sqrtf(nb), eps));
+    mse_out[r] = se / static_cast<float>(H);
+  }
+}
+
+void launch_row_metrics_f32(const float* a, const float* b, float* cos_out, float* mse_out,
+                            long long rows, int H, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(row_metrics_kernel<float>, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256),
+                     0, st, a, b, cos_out, mse_out, rows, H, eps);
+}
+void launch_row_metrics_bf16(const bf16_t* a, const bf16_t* b, float* cos_out, float* mse_out,
+                             long long rows, int H, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(row_metrics_kernel<bf16_t>, dim3(static_cast<unsigned>((rows + 3) / 4)),
+                     dim3(256), 0, st, a, b, cos_out, mse_out, rows, H, eps);
+}
+
 void launch_reduce_residual_norm(const float* partial, int nslab, int M, int N, const bf16_t* res,
                                  bf16_t* x_out, const bf16_t* norm_w, bf16_t* xn_out, float eps,
                                  hipStream_t st) {

@@ -70,6 +70,9 @@ def seq_mask(seq_lens: torch.Tensor, max_seq: int) -> torch.Tensor:
 
 def masked_cosine(a: torch.Tensor, b: torch.Tensor, chunk: int = 256) -> torch.Tensor:
     """Row-wise cosine of two ``[N, S, H]`` tensors, fp32 accumulation, chunked over N."""
+    if a.is_cuda:        # one fused pass over both tensors
+        from .. import ops
+        return ops.cosine_rows(a, b, 1e-12)
     out = torch.empty(a.shape[:2], dtype=torch.float32, device=a.device)
     for i in range(0, a.shape[0], chunk):
         x, y = a[i:i + chunk].float(), b[i:i + chunk].float()

@@ -97,4 +97,13 @@ quick_gelu = ref.quick_gelu
 sample_top_p = ref.sample_top_p
 splice_embeddings = ref.splice_embeddings
 verify_greedy = ref.verify_greedy
-cosine_rows = ref.cosine_rows
+def row_metrics(a, b, eps: float = 1e-8):
+    """``(cosine, mse)`` per row of two equally shaped tensors: one fused pass on a GPU."""
+    if _use_hip(a) and b.is_cuda and a.dtype == b.dtype and a.dtype in (torch.float32, torch.bfloat16) \
+            and a.shape == b.shape and a.shape[-1] % 8 == 0 and not (a.requires_grad or b.requires_grad):
+        return _hip().raw.row_metrics(a.contiguous(), b.contiguous(), float(eps))
+    return ref.row_metrics(a, b, eps)
+
+
+def cosine_rows(a, b, eps: float = 1e-8):
+    return row_metrics(a, b, eps)[0]

@@ -193,3 +193,9 @@ def verify_greedy(draft: torch.Tensor, target_argmax: torch.Tensor):
 def cosine_rows(a: torch.Tensor, b: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
     af, bf = a.float(), b.float()
     return (af * bf).sum(-1) / (af.norm(dim=-1).clamp_min(eps) * bf.norm(dim=-1).clamp_min(eps))
+
+
+def row_metrics(a: torch.Tensor, b: torch.Tensor, eps: float = 1e-8):
+    """``(cosine, mean squared error)`` over the last dim, fp32."""
+    af, bf = a.float(), b.float()
+    return cosine_rows(af, bf, eps), (af - bf).pow(2).mean(-1)

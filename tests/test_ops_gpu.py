@@ -233,3 +233,19 @@ def test_reduce_consumers_match_unfused_bitwise(dev, M):
     posb = (torch.arange(M, device=dev, dtype=torch.int32) * 3) % (Lmax + 4) - 1   # incl. out-of-cache rows
     for a, b in zip(run(True, M, 1, posb), run(False, M, 1, posb)):
         assert same(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_row_metrics(dev, dtype):
+    from eventgpt_amd import ops
+    g = torch.Generator(device=dev).manual_seed(3)
+    a = torch.randn(7, 13, 4096, device=dev, generator=g).to(dtype)
+    b = (a.float() * 0.8 + 0.3 * torch.randn(7, 13, 4096, device=dev, generator=g)).to(dtype)
+    b[0, 0] = 0                                            # a zero row: cosine 0, no NaN
+    cos, mse = ops.row_metrics(a, b)
+    wc, wm = ref.row_metrics(a, b)
+    assert cos.shape == (7, 13) and mse.shape == (7, 13) and cos.dtype == torch.float32
+    assert torch.allclose(cos, wc, atol=1e-4, rtol=1e-4) and torch.allclose(mse, wm, atol=1e-4, rtol=1e-4)
+    assert float(cos[0, 0]) == 0.0 and torch.isfinite(cos).all()
+    from eventgpt_amd.eval.acceptance import masked_cosine
+    assert torch.allclose(masked_cosine(a, b), wc, atol=1e-4, rtol=1e-4)
