@@ -76,7 +76,10 @@ def main():
         cfg.vision_config = ClipVisionConfig(hidden_size=256, intermediate_size=1024,
                                              num_hidden_layers=2, num_attention_heads=4)
         model_name = "small-debug"
-    torch.manual_seed(1234 + rank)
+    # tensor-parallel ranks are shards of ONE model and must see identical inputs;
+    # data-parallel ranks are independent replicas with their own streams
+    data_seed = 0 if (args.parallelism == "tp" and world > 1) else rank
+    torch.manual_seed(1234 + data_seed)
     model = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=1234)
 
     ekw = {} if args.nsplit is None else {"nsplit": args.nsplit}
@@ -98,7 +101,7 @@ def main():
 
     # ---- event prefill: raster -> CLIP preprocess -> ViT -> projector -> pool
     proc = EventImageProcessor(cfg.vision_config.image_size)
-    ev = synthetic_events(seed=rank)
+    ev = synthetic_events(seed=data_seed)
     frames = event_frames(ev, args.frames)
     tens = [proc(f, return_tensors="pt")["pixel_values"][0].to(dev, torch.bfloat16) for f in frames]
     with torch.no_grad():
