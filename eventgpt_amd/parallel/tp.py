@@ -202,6 +202,9 @@ class TensorParallelEngine(GenerationEngine):
 
     def __init__(self, model, group=None, max_len: int = 2048, max_batch: int = 1, **kw):
         self._group_arg = group
+        if (group is not None and dist.is_initialized() and dist.get_world_size(group) > 1
+                and dist.get_backend(group) == "gloo"):
+            kw["use_graph"] = False     # gloo collectives go through host copies: nothing to capture
         super().__init__(model, max_len=max_len, max_batch=max_batch, **kw)
         if self.tp_world > 1:   # samplers read the gathered, full-vocabulary rows
             self.logits = torch.zeros(self.B, self.v_total, dtype=torch.float32, device=self.device)

@@ -363,23 +363,38 @@ class GenerationEngine:
 
     def _capture(self, fn):
         """Capture ``fn`` into a HIP graph.  Warm-up and capture advance the device
-        counters, so they are snapshotted and restored."""
-        saved = [t.clone() for t in (self.step, self.pos, self.done, self.cur_token, self.x)]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fn()  # warm-up (first-launch module load) outside the capture
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        # thread-local capture mode: another host thread driving a second engine on
-        # its own stream must not invalidate this capture
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            fn()
-        for t, s in zip((self.step, self.pos, self.done, self.cur_token, self.x), saved):
-            t.copy_(s)
-        torch.cuda.synchronize()
+        counters, so they are snapshotted and restored (also when the capture fails)."""
+        state = (self.step, self.pos, self.done, self.cur_token, self.x)
+        saved = [t.clone() for t in state]
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()  # warm-up (first-launch module load) outside the capture
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            # thread-local capture mode: another host thread driving a second engine on
+            # its own stream must not invalidate this capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                fn()
+        finally:
+            for t, s in zip(state, saved):
+                t.copy_(s)
+            torch.cuda.synchronize()
         return g
+
+    def _capture_or_eager(self, fn):
+        """``_capture`` that degrades to eager stepping when the step cannot be captured
+        (e.g. a collective backend that does not record into graphs): warns once, turns
+        graphs off for this engine and returns None."""
+        try:
+            return self._capture(fn)
+        except RuntimeError as e:
+            import warnings
+            warnings.warn(f"decode step could not be captured into a HIP graph ({e}); running eagerly")
+            self.use_graph = False
+            return None
 
     def ensure_graphs(self, eos_token_id: Optional[int] = None, greedy: bool = True) -> None:
         """Capture the decode graph for this EOS id now, if it is not captured yet.
@@ -403,11 +418,16 @@ class GenerationEngine:
         if greedy:
             g = self._graph_greedy.get(self.eos)
             if g is None:
-                g = self._graph_greedy[self.eos] = self._capture(self._step_greedy)
+                g = self._capture_or_eager(self._step_greedy)
+                if g is None:
+                    return self._step_greedy()
+                self._graph_greedy[self.eos] = g
             g.replay()
         else:
             if self._graph_logits is None:
-                self._graph_logits = self._capture(self._step_logits)
+                self._graph_logits = self._capture_or_eager(self._step_logits)
+                if self._graph_logits is None:
+                    return self._step_logits()
             self._graph_logits.replay()
 
     # --------------------------------------------------------------- generate
