@@ -461,3 +461,40 @@ def load_any_adapter(path: str, device: str = "cpu") -> Tuple[HiddenAdapterBase,
     ckpt = _load_ckpt(path, device)
     cls = _REGISTRY.get(ckpt.get("adapter_type", "L1_Bottleneck"), HiddenStateAdapter)
     return cls.from_checkpoint_dict(ckpt).to(device), ckpt
+
+
+def self_test(hidden_dim: int = 4096, batch: int = 4, seq: int = 50, device: str = "cpu", iters: int = 10,
+              out=print) -> list:
+    """Build every adapter level on random ``[batch, seq, hidden]`` inputs, time ``iters``
+    forwards, take one loss, and print the parameter table (the reference module's
+    ``__main__`` smoke check, hidden_adapter.py:1454-1522).  Returns the table rows."""
+    import time
+    rows = []
+    g = torch.Generator().manual_seed(0)
+    e = torch.randn(batch, seq, hidden_dim, generator=g).to(device)
+    v = (e + 0.1 * torch.randn(batch, seq, hidden_dim, generator=g).to(device))
+    mask = torch.ones(batch, seq, device=device)
+    for level in range(1, 7):
+        m = create_adapter(level, hidden_dim).to(device).eval()
+        with torch.no_grad():
+            m.align(e, v, mask)
+            if device != "cpu":
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                pred = m.align(e, v, mask)
+            if device != "cpu":
+                torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3 / iters
+        loss = m.compute_loss(e, v, mask)
+        assert pred.shape == e.shape and torch.isfinite(loss["total_loss"])
+        rows.append({"level": LEVEL_NAMES[level], "parameters": m.get_num_parameters(), "forward_ms": ms,
+                     "loss": float(loss["total_loss"])})
+        out(f"{LEVEL_NAMES[level]:>4s}  {rows[-1]['parameters'] / 1e6:8.1f} M params  {ms:8.2f} ms/forward  "
+            f"loss {rows[-1]['loss']:.4f}")
+    return rows
+
+
+if __name__ == "__main__":
+    import sys
+    self_test(device="cuda" if torch.cuda.is_available() and "--cpu" not in sys.argv else "cpu")

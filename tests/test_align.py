@@ -171,3 +171,11 @@ def test_trainer_learns_and_resumes(tmp_path):
           "--learning_rate", "0.01", "--cpu", "--resume", save])
     hist2 = json.load(open(os.path.join(save, "history.json")))
     assert len(hist2["train_loss"]) == 8 and hist2["train_loss"][:6] == hist["train_loss"]
+
+
+def test_adapter_self_test_table():
+    from eventgpt_amd.align.adapters import self_test
+    rows = self_test(hidden_dim=64, batch=2, seq=7, iters=1, out=lambda *_: None)
+    assert [r["level"].split("_")[0] for r in rows] == ["L1", "L2", "L3", "L4", "L5", "L5F"]
+    assert all(r["parameters"] > 0 and r["forward_ms"] >= 0 for r in rows)
+    assert rows[3]["parameters"] > rows[0]["parameters"]          # attention adapter > bottleneck
