@@ -1,16 +1,13 @@
 """Op front-end.
 
-Every op has exactly two implementations:
-
-* ``eventgpt_amd.ops.reference`` — plain PyTorch, fp32 internally.  Runs on CPU
-  tensors and is the oracle the kernels are tested against.
 * ``eventgpt_amd.ops.hip`` — the hand-written gfx950 kernels in the in-tree
-  extension ``eventgpt_amd/_C.so``.  Runs on GPU tensors.
-
-A GPU tensor never silently falls back to the reference path: if the extension
-is missing, the call raises.  The one exception is a call that needs autograd
-(training of adapters / LoRA), which uses differentiable PyTorch-ROCm ops —
-the HIP kernels here are inference kernels.
+  extension ``eventgpt_amd/_C.so``: every inference call on GPU tensors.  If the
+  extension is missing the call raises; there is no quiet fallback.
+* ``eventgpt_amd.ops.reference`` — plain PyTorch, fp32 internally: CPU tensors, and
+  the oracle the kernels are tested against.
+* ``eventgpt_amd.ops.differentiable`` — a GPU call that needs autograd (training of the
+  projector, adapters, LoRA, the decoder): PyTorch-ROCm library ops in the tensors' own
+  dtype, since the HIP kernels have no backward and the oracle upcasts every operand.
 """
 from __future__ import annotations
 
@@ -35,21 +32,39 @@ def _hip():
     return hip
 
 
+def _train(*tensors) -> bool:
+    """GPU tensors in a call that autograd records: take the differentiable library path."""
+    t0 = tensors[0]
+    return (t0.is_cuda and torch.is_grad_enabled()
+            and any(t is not None and t.requires_grad for t in tensors))
+
+
+def _diff():
+    from . import differentiable
+    return differentiable
+
+
 def rmsnorm(x, weight, eps: float = 1e-6):
     if _use_hip(x, weight) and x.dtype == torch.bfloat16:
         return _hip().rmsnorm(x, weight, eps)
+    if _train(x, weight):
+        return _diff().rmsnorm(x, weight, eps)
     return ref.rmsnorm(x, weight, eps)
 
 
 def add_rmsnorm(x, residual, weight, eps: float = 1e-6):
     if _use_hip(x, residual, weight) and x.dtype == torch.bfloat16:
         return _hip().add_rmsnorm(x, residual, weight, eps)
+    if _train(x, residual, weight):
+        return _diff().add_rmsnorm(x, residual, weight, eps)
     return ref.add_rmsnorm(x, residual, weight, eps)
 
 
 def layernorm(x, weight, bias, eps: float = 1e-5):
     if _use_hip(x, weight, bias) and x.dtype == torch.bfloat16:
         return _hip().layernorm(x, weight, bias, eps)
+    if _train(x, weight, bias):
+        return _diff().layernorm(x, weight, bias, eps)
     return ref.layernorm(x, weight, bias, eps)
 
 
@@ -57,18 +72,24 @@ def linear(x, weight, bias=None, act: Optional[str] = None, residual=None):
     if _use_hip(x, weight, bias, residual) and x.dtype == torch.bfloat16 \
             and weight.dtype == torch.bfloat16:
         return _hip().linear(x, weight, bias, act, residual)
+    if _train(x, weight, bias, residual):
+        return _diff().linear(x, weight, bias, act, residual)
     return ref.linear(x, weight, bias, act, residual)
 
 
 def swiglu(gate_up):
     if _use_hip(gate_up) and gate_up.dtype == torch.bfloat16:
         return _hip().swiglu(gate_up)
+    if _train(gate_up):
+        return _diff().swiglu(gate_up)
     return ref.swiglu(gate_up)
 
 
 def apply_rope(x, positions, cos, sin):
     if _use_hip(x) and x.dtype == torch.bfloat16:
         return _hip().apply_rope(x, positions, cos, sin)
+    if _train(x):
+        return _diff().apply_rope(x, positions, cos, sin)
     return ref.apply_rope(x, positions, cos, sin)
 
 
@@ -77,6 +98,8 @@ def attention(q, k, v, causal: bool, scale: Optional[float] = None, q_offset: in
     if _use_hip(q, k, v) and q.dtype == torch.bfloat16 and key_padding_mask is None \
             and _hip().attention_supported(q, k, v):
         return _hip().attention(q, k, v, causal, scale, q_offset)
+    if _train(q, k, v):
+        return _diff().attention(q, k, v, causal, scale, q_offset, key_padding_mask)
     return ref.attention(q, k, v, causal, scale, q_offset, key_padding_mask)
 
 
