@@ -439,7 +439,8 @@ void decode_logits(const Tensor& w, const Tensor& x, const c10::optional<Tensor>
 void commit_token(const Tensor& part_val, const Tensor& part_idx, int64_t n_part,
                   const c10::optional<Tensor>& sampled, const Tensor& embed, const Tensor& x,
                   const Tensor& out_tokens, const Tensor& step, const Tensor& pos,
-                  const Tensor& done, const Tensor& cur_token, int64_t eos) {
+                  const Tensor& done, const Tensor& cur_token, int64_t eos,
+                  const c10::optional<Tensor>& active) {
   check_f32(part_val, "part_val"); check_i32(part_idx, "part_idx"); check_bf16(embed, "embed");
   check_bf16(x, "x"); check_i32(out_tokens, "out_tokens"); check_i32(step, "step");
   check_i32(pos, "pos"); check_i32(done, "done"); check_i32(cur_token, "cur_token");
@@ -449,11 +450,17 @@ void commit_token(const Tensor& part_val, const Tensor& part_idx, int64_t n_part
   const int* sp = nullptr;
   if (sampled.has_value() && sampled->defined()) { check_i32(*sampled, "sampled"); sp = sampled->data_ptr<int>(); }
   else TORCH_CHECK(part_val.numel() >= B * n_part && part_idx.numel() >= B * n_part);
+  const int* ap = nullptr;
+  if (active.has_value() && active->defined()) {
+    check_i32(*active, "active");
+    TORCH_CHECK(active->numel() == B, "commit_token: one active flag per sequence");
+    ap = active->data_ptr<int>();
+  }
   evgpt::launch_commit_token(part_val.data_ptr<float>(), part_idx.data_ptr<int>(), (int)n_part, sp,
                              bptr(embed), bptr_mut(x), out_tokens.data_ptr<int>(),
                              (int)out_tokens.size(1), step.data_ptr<int>(), pos.data_ptr<int>(),
                              done.data_ptr<int>(), cur_token.data_ptr<int>(), (int)eos, (int)B,
-                             (int)H, (int)embed.size(0), cur_stream());
+                             (int)H, (int)embed.size(0), cur_stream(), ap);
 }
 
 // qkv [B,S,(Hq+2Hkv)*D] -> q_out [B,S,Hq*D] (rotated) + cache append at pos0[b]+s
@@ -646,7 +653,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("decode_mlp_up(Tensor w_gate_up, Tensor x, Tensor norm_w, float eps, Tensor(a!) h) -> ()", &decode_mlp_up);
   m.def("logits_partials(int N) -> int", &logits_partials);
   m.def("decode_logits(Tensor w, Tensor x, Tensor? norm_w, float eps, Tensor(a!)? logits, Tensor(b!) part_val, Tensor(c!) part_idx) -> ()", &decode_logits);
-  m.def("commit_token(Tensor part_val, Tensor part_idx, int n_part, Tensor? sampled, Tensor embed, Tensor(a!) x, Tensor(b!) out_tokens, Tensor(c!) step, Tensor(d!) pos, Tensor(e!) done, Tensor(f!) cur_token, int eos) -> ()", &commit_token);
+  m.def("commit_token(Tensor part_val, Tensor part_idx, int n_part, Tensor? sampled, Tensor embed, Tensor(a!) x, Tensor(b!) out_tokens, Tensor(c!) step, Tensor(d!) pos, Tensor(e!) done, Tensor(f!) cur_token, int eos, Tensor? active=None) -> ()", &commit_token);
   m.def("linear_argmax_partials(Tensor x, Tensor w, Tensor? bias) -> (Tensor, Tensor)", &linear_argmax_partials);
   m.def("event_raster(Tensor x, Tensor y, Tensor p, int n_slices, int H, int W, int mode) -> Tensor", &event_raster);
   m.def("event_voxel(Tensor x, Tensor y, Tensor p, Tensor t, int t0, int span, int bins, int H, int W, bool signed_mode, bool by_count) -> (Tensor, Tensor)", &event_voxel);

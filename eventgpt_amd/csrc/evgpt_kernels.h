@@ -74,7 +74,8 @@ void launch_argmax_rows_bf16(const bf16_t* x, long long* out, int rows, int N, h
 void launch_commit_token(const float* part_val, const int* part_idx, int n_part,
                          const int* sampled, const bf16_t* embed, bf16_t* x, int* out_tokens,
                          int max_out, int* step, int* pos, int* done, int* cur_token, int eos,
-                         int B, int H, int vocab, hipStream_t st);
+                         int B, int H, int vocab, hipStream_t st,
+                         const int* active = nullptr);
 
 void launch_patchify(const bf16_t* px, bf16_t* out, int T, int C, int S, int P, int Kp,
                      hipStream_t st);

@@ -412,16 +412,20 @@ void launch_argmax_rows_bf16(const bf16_t* x, long long* out, int rows, int N, h
 // step counter, (b) sets the EOS flag, (c) gathers its embedding row into the
 // residual-stream buffer for the next step and (d) advances the position.
 // One block per sequence; everything the host would otherwise do between two
-// decode steps, so a replayed graph needs no host round trip.
+// decode steps, so a replayed graph needs no host round trip.  `active` (optional,
+// one int per sequence) masks slots that must not advance: a batch scheduler
+// admits or parks sequences by editing it between replays.
 __global__ __launch_bounds__(256) void commit_token_kernel(
     const float* __restrict__ part_val, const int* __restrict__ part_idx, int n_part,
     const int* __restrict__ sampled, const bf16_t* __restrict__ embed, bf16_t* __restrict__ x,
     int* __restrict__ out_tokens, int max_out, int* __restrict__ step, int* __restrict__ pos,
-    int* __restrict__ done, int* __restrict__ cur_token, int eos, int H, int vocab) {
+    int* __restrict__ done, int* __restrict__ cur_token, int eos, int H, int vocab,
+    const int* __restrict__ active) {
   __shared__ float sv[4];
   __shared__ int si[4];
   __shared__ int tok_s;
   const int b = blockIdx.x;
+  if (active && !active[b]) return;   // block-uniform
   if (sampled) {
     if (threadIdx.x == 0) tok_s = sampled[b];
   } else {
@@ -471,9 +475,10 @@ __global__ __launch_bounds__(256) void commit_token_kernel(
 void launch_commit_token(const float* part_val, const int* part_idx, int n_part,
                          const int* sampled, const bf16_t* embed, bf16_t* x, int* out_tokens,
                          int max_out, int* step, int* pos, int* done, int* cur_token, int eos,
-                         int B, int H, int vocab, hipStream_t st) {
+                         int B, int H, int vocab, hipStream_t st, const int* active) {
   hipLaunchKernelGGL(commit_token_kernel, dim3(B), dim3(256), 0, st, part_val, part_idx, n_part,
-                     sampled, embed, x, out_tokens, max_out, step, pos, done, cur_token, eos, H, vocab);
+                     sampled, embed, x, out_tokens, max_out, step, pos, done, cur_token, eos, H, vocab,
+                     active);
 }
 
 }  // namespace evgpt

@@ -353,6 +353,45 @@ class TensorParallelEngine(GenerationEngine):
             raise ValueError("with several sequences use prefill_batch (one commit for all)")
         return super().prefill(embeds, batch, start, None, return_hidden)
 
+    # ------------------------------------------------------ slot-wise scheduling
+    def enable_slot_masks(self) -> None:
+        """Give the commit kernel a per-slot "may advance" mask (all ones).  Captured
+        graphs bake the pointer, so earlier captures are dropped."""
+        if self.active is None:
+            self.active = torch.ones(self.B, dtype=torch.int32, device=self.device)
+            self._graph_greedy.clear()
+            self._graph_logits = None
+
+    @torch.no_grad()
+    def admit(self, slots: Sequence[int], embeds_list: Sequence[torch.Tensor]) -> None:
+        """Start new sequences in ``slots`` while the other slots keep their state:
+        prefill each slot's cache, then pick and commit the first token of exactly those
+        slots (every other slot is masked out of the commit)."""
+        self.enable_slot_masks()
+        if len(slots) != len(embeds_list) or not slots:
+            raise ValueError("one prompt per admitted slot")
+        keep = self.active.clone()
+        for b, emb in zip(slots, embeds_list):
+            if emb.shape[0] > self.l_max:
+                raise ValueError(f"prompt of {emb.shape[0]} tokens exceeds the cache ({self.l_max})")
+            pos0 = torch.zeros(1, dtype=torch.int32, device=self.device)
+            h = self._forward_rows(emb, b, pos0)
+            self.x[b].copy_(h[0, -1])
+            self.pos[b] = emb.shape[0] - 1      # the commit advances it to the prompt length
+            self.step[b] = 0
+            self.done[b] = 0
+        self.active.zero_()
+        self.active[list(slots)] = 1
+        self._logits_and_commit(greedy=True)
+        keep[list(slots)] = 1
+        self.active.copy_(keep)
+
+    def park(self, slots: Sequence[int]) -> None:
+        """Stop advancing ``slots`` (finished or cancelled sequences)."""
+        self.enable_slot_masks()
+        if slots:
+            self.active[list(slots)] = 0
+
     def tokens(self, batch: int) -> torch.Tensor:
         n = int(self.step[batch].item())
         return self.out_tokens[batch, :n].to(torch.long)

@@ -112,6 +112,9 @@ class GenerationEngine:
         self.cur_token = torch.zeros(B, **i32)
         self.sampled = torch.zeros(B, **i32)
         self.sd_result = torch.zeros(4, **i32)  # [n_accepted, next_token, n_emitted, -]
+        # per-sequence "may advance" flags read by the commit kernel; None = all.  A batch
+        # scheduler allocates them (TensorParallelEngine.enable_slot_masks).
+        self.active = None
         self.eos = int(cfg.eos_token_id if cfg.eos_token_id is not None else -1)
         # captured graphs bake the EOS id (a launch argument), so they are keyed by it
         self._graph_greedy = {}
@@ -346,12 +349,12 @@ class GenerationEngine:
         if greedy:
             raw.commit_token(self.part_val, self.part_idx, self.n_part, None, self.embed, self.x,
                              self.out_tokens, self.step, self.pos, self.done, self.cur_token,
-                             self.eos)
+                             self.eos, self.active)
 
     def _commit_sampled(self) -> None:
         self.raw.commit_token(self.part_val, self.part_idx, self.n_part, self.sampled, self.embed,
                               self.x, self.out_tokens, self.step, self.pos, self.done,
-                              self.cur_token, self.eos)
+                              self.cur_token, self.eos, self.active)
 
     def _step_greedy(self) -> None:
         self._layers_step()
