@@ -391,6 +391,9 @@ class TensorParallelEngine(GenerationEngine):
         self.enable_slot_masks()
         if slots:
             self.active[list(slots)] = 0
+            # a parked slot still rides through the batched kernels: with position 0 its
+            # attention reads one key instead of a finished sequence's whole cache
+            self.pos[list(slots)] = 0
 
     def tokens(self, batch: int) -> torch.Tensor:
         n = int(self.step[batch].item())
