@@ -98,9 +98,13 @@ class LoRATrainer:
         """Host-only work (runs on the prefetch thread)."""
         si, qi = meta["sample_idx"], meta["question_idx"]
         text = meta.get("egpt_text", "")
-        if si >= len(ds) or qi >= len(self.questions) or not text:
+        if si >= len(ds) or qi >= len(self.questions):
             return None
-        gen = self.tok.encode(text, add_special_tokens=False)[:target_len]
+        # The answer is re-tokenised from its text; a store whose tokenizer cannot
+        # round-trip the ids (random weights over a byte vocabulary decode to "")
+        # falls back to the drafter's recorded token ids.
+        gen = self.tok.encode(text, add_special_tokens=False) if text else list(meta.get("egpt_tokens", []))
+        gen = gen[:target_len]
         if len(gen) < MIN_LEN:
             return None
         inp = self.prepare_input(ds, ds[si], self.questions[qi])

@@ -181,6 +181,7 @@ def run_extraction(extractor: HiddenStateExtractor, ds: InstructionDataset, ques
             writer.add_sample(res["egpt_hidden"], res["vl_hidden"],
                               {"sample_idx": si, "question_idx": qi, "question": questions[qi],
                                "egpt_text": res["egpt_text"], "vl_text": res["vl_text"],
+                               "egpt_tokens": [int(t) for t in res.get("egpt_tokens", [])],
                                "seq_len": res["seq_len"]})
             stats["new"] += 1
         if log_every and (k + 1) % log_every == 0:

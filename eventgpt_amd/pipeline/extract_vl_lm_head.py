@@ -33,11 +33,24 @@ def save_lm_head(weight: torch.Tensor, out_path: str, model_id: str) -> Dict:
 
 def main(argv=None) -> str:
     p = argparse.ArgumentParser(description="Extract the verifier LM head")
-    p.add_argument("--model_path", required=True, help="checkpoint directory of the verifier")
+    p.add_argument("--model_path", default=None, help="checkpoint directory of the verifier")
+    p.add_argument("--random_init", default=None, choices=["7b", "tiny"],
+                   help="the randomly initialised verifier of the synthetic flows (same seed as the extractors)")
     p.add_argument("--output", default=None)
     args = p.parse_args(argv)
     out = args.output or os.path.join(os.getcwd(), "data", "vl_lm_head.pt")
-    w = extract_lm_head(args.model_path)
+    if args.random_init:
+        from ..models.video_llava import VideoLlavaConfig, VideoLlavaModel
+        cfg = VideoLlavaConfig.video_llava_7b() if args.random_init == "7b" else VideoLlavaConfig.tiny()
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        dtype = torch.bfloat16 if dev == "cuda" else torch.float32
+        vl = VideoLlavaModel.from_config(cfg, dtype, dev, seed=1)
+        w = vl.language_model.lm_head.weight.detach().float().cpu().contiguous()
+        args.model_path = f"random_init:{args.random_init}"
+    elif args.model_path:
+        w = extract_lm_head(args.model_path)
+    else:
+        p.error("--model_path or --random_init")
     save_lm_head(w, out, args.model_path)
     print(f"saved {tuple(w.shape)} fp32 ({w.numel() * 4 / 2 ** 20:.1f} MiB) -> {out}")
     return out

@@ -74,6 +74,30 @@ def test_l6_trainer_end_to_end(tmp_path):
     assert cfg["lora"]["r"] == 4 and cfg["parameters"]["trainable"] > 0
 
 
+def test_l6_sample_falls_back_to_recorded_token_ids():
+    """An answer whose text decoded to "" (ids outside the tokenizer's round-trip range)
+    is trained on from the drafter's recorded ids instead of being dropped."""
+    from eventgpt_amd.align import train_lora as TL
+
+    class Tok:
+        def encode(self, text, add_special_tokens=False):
+            return [ord(c) for c in text]
+
+    class DS(list):
+        pass
+
+    t = TL.LoRATrainer.__new__(TL.LoRATrainer)
+    t.tok, t.questions = Tok(), ["q"]
+    t.prepare_input = lambda ds, sample, q: {"input_ids": torch.zeros(1, 3, dtype=torch.long)}
+    ds = DS([{}])
+    meta = {"sample_idx": 0, "question_idx": 0, "egpt_text": "", "egpt_tokens": list(range(1000, 1012))}
+    got = t._prepare_sample(ds, meta, 8)
+    assert got["gen_token_ids"].tolist() == list(range(1000, 1008))
+    assert t._prepare_sample(ds, dict(meta, egpt_tokens=[]), 8) is None
+    assert t._prepare_sample(ds, dict(meta, egpt_text="hello world"), 8)["gen_token_ids"].tolist() == \
+        [ord(c) for c in "hello wo"]
+
+
 @pytest.mark.timeout(240)
 def test_l6_trainer_two_ranks_gloo(tmp_path):
     """Two data-parallel ranks: samples are split, gradients averaged once per optimizer
