@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1,
                     help="event streams decoded together per engine (32 = the batched serving config)")
     ap.add_argument("--nsplit", type=int, default=None, help="KV splits of the decode attention")
+    ap.add_argument("--weight-format", choices=["bf16", "nf4", "fp4"], default="bf16",
+                    help="nf4/fp4: the reference's 4-bit rows (bitsandbytes load_in_4bit); not the headline config")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,6 +85,8 @@ def main():
     model = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=1234)
 
     ekw = {} if args.nsplit is None else {"nsplit": args.nsplit}
+    if args.weight_format != "bf16":
+        ekw["weight_format"] = args.weight_format
     tp = args.parallelism == "tp" and world > 1
     if tp or args.batch > 1:
         from eventgpt_amd.parallel.tp import TensorParallelEngine
@@ -166,7 +170,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 4),
             "higher_is_better": True,
             "scaling": "strong" if tp else "weak",
-            "vs_baseline": round(tok_s / BASELINE_DECODE_TOK_S, 3), "dtype": "bf16",
+            "vs_baseline": round(tok_s / BASELINE_DECODE_TOK_S, 3),
+            "dtype": "bf16" if args.weight_format == "bf16" else f"bf16 compute, {args.weight_format} weights",
             "data": "synthetic event stream, random-init weights",
             "event_prefill_ms": round(prefill_ms, 3),
             "event_prefill_vs_baseline": round(BASELINE_PREFILL_MS / prefill_ms, 3),

@@ -426,6 +426,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--event_image_key", default="event_image")
     p.add_argument("--egpt_model_path", default=None)
     p.add_argument("--vl_model_path", default=None)
+    from ..quant import add_quant_args
+    add_quant_args(p)
     p.add_argument("--random_init", default=None, choices=["7b", "small"],
                    help="random weights (and untrained adapters when --adapter_dir is absent)")
     p.add_argument("--stage_samples", type=int, default=20)
@@ -470,6 +472,8 @@ def load_everything(args):
         vl = VideoLlavaModel.from_pretrained(args.vl_model_path, bf, device=dev)
         etok = load_tokenizer(args.egpt_model_path)
         vproc = VideoProcessor(vl.config, load_tokenizer(args.vl_model_path))
+    from ..quant import apply_quant_args
+    apply_quant_args(args, egpt, vl)
     ckpts = find_adapter_checkpoints(args.adapter_dir)
     if ckpts:
         adapters = {lv: load_any_adapter(p, dev)[0] for lv, p in ckpts.items()}
@@ -530,7 +534,7 @@ def main(argv=None) -> Dict:
     result = {"timestamp": ts, "config": {"dataset_dir": args.dataset_dir, "max_samples": args.max_samples,
                                           "max_new_tokens": args.max_new_tokens, "gamma": args.gamma,
                                           "warmup": args.warmup, "data": data_kind,
-                                          "weights": args.random_init or "checkpoint",
+                                          "weights": args.random_init or "checkpoint", "weight_format": args.quant_type if args.use_4bit else "bf16",
                                           "adapters": sorted(adapters)},
               "n_measured": len(samples), "stage_timing": stage_timing,
               "aggregate": aggregate(samples, configs), "samples": samples}

@@ -239,6 +239,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--dataset_dir", default=None, help="instruction dataset; synthetic if omitted")
     p.add_argument("--eventgpt_model_path", default=None)
     p.add_argument("--videollava_model", default=None)
+    from ..quant import add_quant_args
+    add_quant_args(p)
     p.add_argument("--random_init", default=None, choices=["7b", "tiny"])
     p.add_argument("--max_samples", type=int, default=-1)
     p.add_argument("--max_new_tokens", type=int, default=50)
@@ -270,7 +272,8 @@ def main(argv=None) -> Dict:
         data_kind = "synthetic"
     ds = InstructionDataset(args.dataset_dir, args.max_samples + args.warmup if args.max_samples > 0 else -1)
     largs = argparse.Namespace(device=args.device, random_init=args.random_init,
-                               egpt_model_path=args.eventgpt_model_path, vl_model_path=args.videollava_model)
+                               egpt_model_path=args.eventgpt_model_path, vl_model_path=args.videollava_model,
+                               use_4bit=args.use_4bit, quant_type=args.quant_type)
     egpt, tok, vl, vproc = load_models(largs)
     adapter = None
     if args.use_token_adapter and args.token_adapter_path:
@@ -297,7 +300,7 @@ def main(argv=None) -> Dict:
         rec["sample"] = i
         results.append(rec)
     stats = compute_statistics(results)
-    config = {"data": data_kind, "weights": args.random_init or "checkpoint", "num_frames": args.num_frames,
+    config = {"data": data_kind, "weights": args.random_init or "checkpoint", "weight_format": args.quant_type if args.use_4bit else "bf16", "num_frames": args.num_frames,
               "max_new_tokens": args.max_new_tokens, "device": str(args.device), "memory": gpu_memory_mb()}
     out_dir = args.output_dir or os.path.join(os.getcwd(), "tasks")
     paths = write_report(stats, results, out_dir, ts, config)

@@ -153,6 +153,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--adapter_dir", default=None)
     p.add_argument("--egpt_model_path", default=None)
     p.add_argument("--vl_model_path", default=None)
+    from ..quant import add_quant_args
+    add_quant_args(p)
     p.add_argument("--random_init", default=None, choices=["7b", "small"])
     p.add_argument("--event_image_key", default="event_image")
     p.add_argument("--warmup", type=int, default=1)
@@ -223,7 +225,7 @@ def main(argv=None) -> Dict:
             if si >= args.warmup:
                 samples.append(r)
     agg = aggregate(samples)
-    result = {"timestamp": ts, "config": {"data": data_kind, "weights": args.random_init or "checkpoint",
+    result = {"timestamp": ts, "config": {"data": data_kind, "weights": args.random_init or "checkpoint", "weight_format": args.quant_type if args.use_4bit else "bf16",
                                           "max_new_tokens": args.max_new_tokens,
                                           "max_draft_tokens": args.max_draft_tokens, "methods": list(bench.runners)},
               "aggregate": agg, "samples": samples}

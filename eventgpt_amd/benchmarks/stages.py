@@ -366,6 +366,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--dataset_dir", default=None, help="instruction dataset; synthetic if omitted")
     p.add_argument("--eventgpt_model_path", default=None)
     p.add_argument("--videollava_model", default=None)
+    from ..quant import add_quant_args
+    add_quant_args(p)
     p.add_argument("--random_init", default=None, choices=["7b", "tiny"])
     p.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
     p.add_argument("--max_samples", type=int, default=None)
@@ -405,7 +407,8 @@ def main(argv=None) -> Dict:
         data_kind = "synthetic"
     ds = InstructionDataset(args.dataset_dir, n_samples if args.max_samples else -1)
     largs = argparse.Namespace(device=args.device, random_init=args.random_init,
-                               egpt_model_path=args.eventgpt_model_path, vl_model_path=args.videollava_model)
+                               egpt_model_path=args.eventgpt_model_path, vl_model_path=args.videollava_model,
+                               use_4bit=args.use_4bit, quant_type=args.quant_type)
     egpt, tok, vl, vproc = load_models(largs)
     frames = 1 if args.compare_1vs8 else args.num_frames
     key = "event_image_1f" if args.compare_1vs8 else "event_image"
@@ -433,7 +436,7 @@ def main(argv=None) -> Dict:
             print(f"[stages] decoupling check: identical tokens = {decoupling['identical_tokens']}, hooks cover "
                   f"{100 * decoupling['hook_coverage']:.0f} % of the monolithic time")
     summaries = {k: summarize_5stage(v, k) for k, v in records.items() if v}
-    result = {"timestamp": ts, "config": {"data": data_kind, "weights": args.random_init or "checkpoint",
+    result = {"timestamp": ts, "config": {"data": data_kind, "weights": args.random_init or "checkpoint", "weight_format": args.quant_type if args.use_4bit else "bf16",
                                           "num_frames": frames, "from_npy": args.from_npy,
                                           "max_new_tokens": args.max_new_tokens, "device": str(args.device)},
               "summaries": summaries, "memory": gpu_memory_mb(),

@@ -42,6 +42,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--event_frame", type=str, required=True)
     # extensions
     p.add_argument("--random_init", choices=["7b", "stub125m", "tiny"], default=None)
+    from ..quant import add_quant_args
+    add_quant_args(p)
     p.add_argument("--device", type=str, default=None)
     p.add_argument("--dtype", choices=["bfloat16", "float32"], default=None)
     p.add_argument("--num_frames", type=int, default=DEFAULT_NUM_EVENT_FRAMES)
@@ -87,6 +89,11 @@ def load_model(args):
 def run(argv: Optional[Sequence[str]] = None) -> str:
     args = build_parser().parse_args(argv)
     model, tokenizer, device, dtype = load_model(args)
+    if args.use_4bit and device.type != "cuda":
+        raise SystemExit("--use_4bit selects the GPU engine's weight format; on the CPU use "
+                         "eventgpt_amd.quant.fake_quantize_model_ to study 4-bit quality")
+    from ..quant import apply_quant_args
+    apply_quant_args(args, model)
     if getattr(model.config, "mm_use_im_patch_token", True):
         tokenizer.add_tokens([DEFAULT_EVENT_PATCH_TOKEN], special_tokens=True)
     if getattr(model.config, "mm_use_im_start_end", False):

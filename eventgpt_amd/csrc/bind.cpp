@@ -360,6 +360,91 @@ void decode_qkv(const Tensor& x, const Tensor& norm_w, const Tensor& w_qkv, cons
                               (int)D, (int)k_cache.size(2), (int)K, cur_stream(), one_seq ? 1 : 0);
 }
 
+// ---- 4-bit codebook weights: `packed` uint8 [N, K/2], `absmax` fp32 [N, K/64], `code` a
+// host bf16 tensor with the 16 codebook entries (read here on the host, so it must not
+// live on the device: these ops run inside graph captures)
+static evgpt::W4Desc w4_desc(const Tensor& packed, const Tensor& absmax, const Tensor& code,
+                             int64_t N, int64_t K) {
+  TORCH_CHECK(packed.is_cuda() && packed.scalar_type() == at::kByte && packed.is_contiguous(),
+              "w4: packed must be a contiguous uint8 device tensor");
+  check_f32(absmax, "absmax");
+  TORCH_CHECK(K % 64 == 0 && packed.numel() == N * (K / 2) && absmax.numel() == N * (K / 64),
+              "w4: packed/absmax do not match [", N, ",", K, "]");
+  TORCH_CHECK(!code.is_cuda() && code.scalar_type() == at::kBFloat16 && code.numel() == 16 &&
+              code.is_contiguous(), "w4: code must be a host bf16 tensor of 16 entries");
+  const uint16_t* c = reinterpret_cast<const uint16_t*>(code.data_ptr());
+  evgpt::W4Desc d{};
+  d.absmax = absmax.data_ptr<float>();
+  for (int e = 0; e < 16; ++e) {
+    d.code.lo[e >> 2] |= static_cast<unsigned int>(c[e] & 0xFF) << (8 * (e & 3));
+    d.code.hi[e >> 2] |= static_cast<unsigned int>(c[e] >> 8) << (8 * (e & 3));
+  }
+  return d;
+}
+
+Tensor w4_dequant(const Tensor& packed, const Tensor& absmax, const Tensor& code,
+                  const c10::optional<Tensor>& out) {
+  TORCH_CHECK(packed.dim() == 2, "w4_dequant: packed [N, K/2]");
+  const int64_t N = packed.size(0), K = packed.size(1) * 2;
+  const evgpt::W4Desc d = w4_desc(packed, absmax, code, N, K);
+  Tensor o = out.has_value() ? *out : at::empty({N, K}, packed.options().dtype(at::kBFloat16));
+  check_bf16(o, "out");
+  TORCH_CHECK(o.numel() == N * K, "w4_dequant: out size");
+  evgpt::launch_w4_dequant(packed.data_ptr<uint8_t>(), d.absmax, d.code, bptr_mut(o), N, (int)K,
+                           cur_stream());
+  return o;
+}
+
+void decode_qkv_w4(const Tensor& x, const Tensor& norm_w, const Tensor& packed, const Tensor& absmax,
+                   const Tensor& code, const Tensor& q_out, const Tensor& k_cache, const Tensor& v_cache,
+                   const Tensor& cos, const Tensor& sin, const Tensor& pos, double eps, int64_t Hq,
+                   int64_t Hkv, int64_t D, bool one_seq) {
+  check_bf16(x, "x"); check_bf16(norm_w, "norm_w");
+  check_bf16(q_out, "q_out"); check_bf16(k_cache, "k_cache"); check_bf16(v_cache, "v_cache");
+  check_f32(cos, "cos"); check_f32(sin, "sin"); check_i32(pos, "pos");
+  const int64_t B = x.size(0), K = x.size(1);
+  TORCH_CHECK(x.dim() == 2 && B <= evgpt::gemv_w4_max_batch() && norm_w.numel() == K);
+  const evgpt::W4Desc d = w4_desc(packed, absmax, code, (Hq + 2 * Hkv) * D, K);
+  TORCH_CHECK(D % 16 == 0 && q_out.numel() == B * Hq * D && pos.numel() == (one_seq ? 1 : B));
+  TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(0) == (one_seq ? 1 : B) && k_cache.size(1) == Hkv &&
+              k_cache.size(3) == D && v_cache.sizes() == k_cache.sizes());
+  TORCH_CHECK(cos.size(-1) == D / 2 && cos.size(0) >= k_cache.size(2),
+              "decode_qkv_w4: rope table shorter than the cache");
+  TORCH_CHECK(B * K * 2 <= 96 * 1024);
+  evgpt::launch_gemv_qkv_rope(reinterpret_cast<const evgpt::bf16_t*>(packed.data_ptr<uint8_t>()), bptr(x),
+                              bptr(norm_w), (float)eps, bptr_mut(q_out), bptr_mut(k_cache),
+                              bptr_mut(v_cache), cos.data_ptr<float>(), sin.data_ptr<float>(),
+                              pos.data_ptr<int>(), (int)B, (int)Hq, (int)Hkv, (int)D,
+                              (int)k_cache.size(2), (int)K, cur_stream(), one_seq ? 1 : 0, &d);
+}
+
+// y (in place) = y + W4 @ xin
+void decode_gemv_residual_w4(const Tensor& packed, const Tensor& absmax, const Tensor& code,
+                             const Tensor& xin, const Tensor& y) {
+  check_bf16(xin, "xin"); check_bf16(y, "y");
+  TORCH_CHECK(xin.dim() == 2 && packed.dim() == 2);
+  const int64_t B = xin.size(0), K = xin.size(1), N = packed.size(0);
+  const evgpt::W4Desc d = w4_desc(packed, absmax, code, N, K);
+  TORCH_CHECK(y.numel() == B * N && N % 4 == 0);
+  TORCH_CHECK(B <= evgpt::gemv_w4_max_batch() && B * K * 2 <= 96 * 1024);
+  evgpt::launch_gemv(reinterpret_cast<const evgpt::bf16_t*>(packed.data_ptr<uint8_t>()), bptr(xin),
+                     bptr_mut(y), nullptr, bptr(y), nullptr, 0.f, 0, (int)B, (int)N, (int)K,
+                     cur_stream(), &d);
+}
+
+void decode_mlp_up_w4(const Tensor& packed, const Tensor& absmax, const Tensor& code, const Tensor& x,
+                      const Tensor& norm_w, double eps, const Tensor& h) {
+  check_bf16(x, "x"); check_bf16(norm_w, "norm_w"); check_bf16(h, "h");
+  TORCH_CHECK(x.dim() == 2 && packed.dim() == 2);
+  const int64_t B = x.size(0), K = x.size(1), I = packed.size(0) / 2;
+  const evgpt::W4Desc d = w4_desc(packed, absmax, code, 2 * I, K);
+  TORCH_CHECK(h.numel() == B * I && I % 2 == 0 && norm_w.numel() == K);
+  TORCH_CHECK(B <= evgpt::gemv_w4_max_batch() && B * K * 2 <= 96 * 1024);
+  evgpt::launch_gemv_swiglu(reinterpret_cast<const evgpt::bf16_t*>(packed.data_ptr<uint8_t>()), bptr(x),
+                            bptr_mut(h), bptr(norm_w), (float)eps, (int)B, (int)I, (int)K, cur_stream(),
+                            &d);
+}
+
 void decode_attn(const Tensor& q, const Tensor& k_cache, const Tensor& v_cache, const Tensor& out,
                  const Tensor& part_o, const Tensor& part_ml, const Tensor& pos, int64_t nsplit,
                  double scale) {
@@ -649,6 +734,11 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("decode_qkv(Tensor x, Tensor norm_w, Tensor w_qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos, float eps, int Hq, int Hkv, int D, bool one_seq=False) -> ()", &decode_qkv);
   m.def("decode_attn(Tensor q, Tensor k_cache, Tensor v_cache, Tensor(a!) out, Tensor(b!) part_o, Tensor(c!) part_ml, Tensor pos, int nsplit, float scale) -> ()", &decode_attn);
   m.def("decode_gemv_residual(Tensor w, Tensor xin, Tensor(a!) y) -> ()", &decode_gemv_residual);
+  m.def("w4_dequant(Tensor packed, Tensor absmax, Tensor code, Tensor(a!)? out=None) -> Tensor", &w4_dequant);
+  m.def("gemv_w4_max_batch() -> int", []() { return (int64_t)evgpt::gemv_w4_max_batch(); });
+  m.def("decode_qkv_w4(Tensor x, Tensor norm_w, Tensor packed, Tensor absmax, Tensor code, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos, float eps, int Hq, int Hkv, int D, bool one_seq=False) -> ()", &decode_qkv_w4);
+  m.def("decode_gemv_residual_w4(Tensor packed, Tensor absmax, Tensor code, Tensor xin, Tensor(a!) y) -> ()", &decode_gemv_residual_w4);
+  m.def("decode_mlp_up_w4(Tensor packed, Tensor absmax, Tensor code, Tensor x, Tensor norm_w, float eps, Tensor(a!) h) -> ()", &decode_mlp_up_w4);
   m.def("decode_gemv(Tensor w, Tensor xin, Tensor(a!) y, bool accumulate) -> ()", &decode_gemv);
   m.def("decode_mlp_up(Tensor w_gate_up, Tensor x, Tensor norm_w, float eps, Tensor(a!) h) -> ()", &decode_mlp_up);
   m.def("logits_partials(int N) -> int", &logits_partials);

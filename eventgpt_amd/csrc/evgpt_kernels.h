@@ -10,16 +10,25 @@ typedef unsigned short bf16_t;
 // ---- gemv.hip (decode, batch <= gemv_max_batch())
 int gemv_max_batch();
 int gemv_logits_grid(int N);
+// 4-bit weights with a 16-entry bf16 codebook: lo[g] / hi[g] hold the low / high bytes
+// of entries 4g..4g+3 (entry 4g in byte 0).  A launcher given a W4Desc reads `W` as
+// [N][K/2] code bytes and `absmax` as [N][K/64] fp32 scales (K % 64 == 0).
+struct W4Code { unsigned int lo[4], hi[4]; };
+struct W4Desc { const float* absmax; W4Code code; };
+int gemv_w4_max_batch();
+void launch_w4_dequant(const unsigned char* packed, const float* absmax, const W4Code& code,
+                       bf16_t* out, long long n_rows, int K, hipStream_t st);
 void launch_gemv(const bf16_t* W, const bf16_t* x, bf16_t* y, const bf16_t* bias,
                  const bf16_t* res, const bf16_t* norm_w, float eps, int act, int B, int N,
-                 int K, hipStream_t st);
+                 int K, hipStream_t st, const W4Desc* w4 = nullptr);
 void launch_gemv_swiglu(const bf16_t* W_gate_up, const bf16_t* x, bf16_t* y,
-                        const bf16_t* norm_w, float eps, int B, int inter, int K, hipStream_t st);
+                        const bf16_t* norm_w, float eps, int B, int inter, int K, hipStream_t st,
+                        const W4Desc* w4 = nullptr);
 void launch_gemv_qkv_rope(const bf16_t* W_qkv, const bf16_t* x, const bf16_t* norm_w, float eps,
                           bf16_t* q_out, bf16_t* k_cache, bf16_t* v_cache, const float* cos_tab,
                           const float* sin_tab, const int* pos, int B, int n_q_heads,
                           int n_kv_heads, int head_dim, int l_max, int K, hipStream_t st,
-                          int rows_one_seq = 0);
+                          int rows_one_seq = 0, const W4Desc* w4 = nullptr);
 void launch_gemv_logits(const bf16_t* W, const bf16_t* x, const bf16_t* norm_w, float eps,
                         float* logits, float* part_val, int* part_idx, int B, int N, int K,
                         hipStream_t st);

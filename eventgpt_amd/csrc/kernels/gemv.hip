@@ -22,10 +22,20 @@
 //     pairs j, j+D/2), fp32 logits + per-block argmax partials.
 // Positions / cache lengths are read from device memory so a captured graph can
 // be replayed for every token.
+//
+// 4-bit weights (template Q = 1): the same kernels stream a 16-entry-codebook
+// format (NF4 or any other table): [N][K/2] code bytes + one fp32 scale per 64
+// weights.  A lane's 16-byte load is 32 weights that share one scale, so the
+// scale is applied once per load; codes become bf16 pairs for v_dot2c through
+// v_perm_b32 lookups in a register-resident table (no LDS traffic for the
+// table).  x is always staged in LDS in this mode (a lane needs 64 bytes of x per
+// 16 bytes of weights), XOR-swizzled so that the 64-byte lane stride is
+// conflict-free.
 #include <cstdlib>
 
 #include "common.h"
 #include "../evgpt_kernels.h"
+#include "w4.h"
 
 namespace evgpt {
 
@@ -56,6 +66,10 @@ struct GemvParams {
   float* logits;         // [B][N] or null
   float* part_val;       // [B][gridDim.x]
   int* part_idx;
+  // Q = 1: W holds [N][K/2] code bytes (byte j of each 32-bit word = codes of weights
+  // j and 4+j of that word's 8 consecutive weights, low nibble first)
+  const float* absmax;   // [N][K/64]
+  W4Code code;           // byte planes of the 16 bf16 codebook entries
 };
 
 #ifndef EVGPT_GEMV_PRE
@@ -87,8 +101,19 @@ __device__ __forceinline__ void unit_rows(const GemvParams& p, int u, int (&row)
   }
 }
 
-template <int B, int P, int E, int KS>
-__global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
+// x chunk i (16 bytes) sits at this slot of the LDS image.  Q = 1 lanes read chunks
+// 4c..4c+3 of consecutive c: the XOR spreads a 16-lane group over all 64 banks.
+template <int Q>
+__device__ __forceinline__ int xs_slot(int i) {
+  if constexpr (Q) return i ^ ((i >> 4) & 3);
+  else return i;
+}
+
+template <int B, int P, int E, int KS, int Q>
+// 4-bit: the expansion is VALU work that needs other waves to hide under, so the
+// register budget is capped for 4 waves per SIMD (the compiler otherwise hoists every
+// row's expansion and ends at 1-2)
+__global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : 1) void gemv_kernel(GemvParams p) {
   static_assert(KS == 1 || KS == 2 || KS == 4, "KS waves per unit");
   static_assert(E != E_LOGITS || KS == 1, "logits epilogue runs one wave per unit");
   constexpr int UPB = GEMV_WAVES / KS;  // units per block iteration
@@ -100,12 +125,17 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
   u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem + PART_BYTES + 64);  // [B][K/8]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int ks = wid % KS, ub_slot = wid / KS;
-  const int nchunk = p.K >> 3;
+  const int nchunk = p.K >> 3;              // 16-byte chunks of one x row
+  const int nwc = Q ? (p.K >> 5) : nchunk;  // 16-byte chunks of one weight row
+  const size_t row_bytes = Q ? static_cast<size_t>(p.K >> 1) : static_cast<size_t>(p.K) * 2;
+  const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
+  const int nblk = p.K >> 6;                // scales per weight row (Q)
+  constexpr bool STAGE = (P == P_RMSNORM) || Q;  // x goes through LDS
 
-  // this wave's slice of the K range, in 16-byte chunks
-  const int cper = (nchunk + KS - 1) / KS;
+  // this wave's slice of the K range, in 16-byte weight chunks
+  const int cper = (nwc + KS - 1) / KS;
   const int c_begin = ks * cper;
-  const int c_end = min(c_begin + cper, nchunk);
+  const int c_end = min(c_begin + cper, nwc);
   const int n_units = (p.N + R - 1) / R;
   const int n_ub = (n_units + UPB - 1) / UPB;
 
@@ -113,24 +143,27 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
   // The weights do not depend on x, so the first PRE chunk-iterations of this
   // wave's first unit are requested before the norm: the HBM round trip of the
   // first weight bytes then overlaps the reduction instead of following it.
-  constexpr int PRE = EVGPT_GEMV_PRE;
+  constexpr int PRE = Q ? 0 : EVGPT_GEMV_PRE;  // 4-bit: the registers go to the expansion
   u32x4_t pre[PRE > 0 ? PRE : 1][R];
-  if constexpr (P == P_RMSNORM) {
-    {
-      const int u = blockIdx.x * UPB + ub_slot;
-      int row[R];
-      unit_rows<E>(p, u < n_units ? u : n_units - 1, row);
+  float pre_sc[PRE > 0 ? PRE : 1][R];
+  if constexpr (STAGE) {
+    const int u = blockIdx.x * UPB + ub_slot;
+    int row[R];
+    unit_rows<E>(p, u < n_units ? u : n_units - 1, row);
 #pragma unroll
-      for (int i = 0; i < PRE; ++i) {
-        const int c = c_begin + lane + 64 * i;
-        const int cc = c < c_end ? c : 0;  // out-of-slice lanes load a valid address and drop it
+    for (int i = 0; i < PRE; ++i) {
+      const int c = c_begin + lane + 64 * i;
+      const int cc = c < c_end ? c : 0;  // out-of-slice lanes load a valid address and drop it
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int rr = row[r] < p.N ? row[r] : p.N - 1;
-          pre[i][r] = load_stream16(p.W + static_cast<size_t>(rr) * p.K + cc * 8);
-        }
+      for (int r = 0; r < R; ++r) {
+        const int rr = row[r] < p.N ? row[r] : p.N - 1;
+        pre[i][r] = load_stream16(Wb + static_cast<size_t>(rr) * row_bytes + static_cast<size_t>(cc) * 16);
+        if constexpr (Q)
+          pre_sc[i][r] = __builtin_nontemporal_load(p.absmax + static_cast<size_t>(rr) * nblk + (cc >> 1));
       }
     }
+  }
+  if constexpr (P == P_RMSNORM) {
     constexpr int XC = 2;  // x chunks a thread keeps in registers between the two passes
     if (nchunk <= XC * GEMV_WAVES * 64) {
       u32x4_t nw[XC];
@@ -167,7 +200,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
             const float hi = bf16_to_f32(f32_to_bf16(bf16hi(xv[i][j]) * rstd)) * bf16hi(nw[i][j]);
             o[j] = pack_bf16x2(lo, hi);
           }
-          if (c < nchunk) xs[b * nchunk + c] = o;
+          if (c < nchunk) xs[b * nchunk + xs_slot<Q>(c)] = o;
         }
       }
     } else {
@@ -194,10 +227,16 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
             const float hi = bf16_to_f32(f32_to_bf16(bf16hi(v[i]) * rstd)) * bf16hi(w[i]);
             o[i] = pack_bf16x2(lo, hi);
           }
-          xs[b * nchunk + c] = o;
+          xs[b * nchunk + xs_slot<Q>(c)] = o;
         }
       }
     }
+    __syncthreads();
+  } else if constexpr (Q) {
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+      for (int c = tid; c < nchunk; c += blockDim.x)
+        xs[b * nchunk + xs_slot<Q>(c)] = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
     __syncthreads();
   }
 
@@ -223,11 +262,13 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
     const bool unit_ok = u < n_units;
     int row[R];
     unit_rows<E>(p, unit_ok ? u : n_units - 1, row);
-    const bf16_t* wp[R];
+    const unsigned char* wp[R];
+    const float* sp[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int rr = row[r] < p.N ? row[r] : p.N - 1;  // clamp; out-of-range rows are discarded
-      wp[r] = p.W + static_cast<size_t>(rr) * p.K;
+      wp[r] = Wb + static_cast<size_t>(rr) * row_bytes;
+      if constexpr (Q) sp[r] = p.absmax + static_cast<size_t>(rr) * nblk;
     }
     float acc[R][B];
 #pragma unroll
@@ -261,32 +302,66 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(GemvParams p) {
       }
     }
 
-    auto consume = [&](const u32x4_t (&wv)[R], int c) {
+    auto consume = [&](const u32x4_t (&wv)[R], const float (&sc)[R], int c) {
+      if constexpr (Q) {
+        u32x4_t xv[B][4];
 #pragma unroll
-      for (int b = 0; b < B; ++b) {
-        u32x4_t xv;
-        if constexpr (P == P_RMSNORM) xv = xs[b * nchunk + c];
-        else xv = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+        for (int b = 0; b < B; ++b)
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r][b] = dot8_bf16(wv[r], xv, acc[r][b]);
+          for (int j = 0; j < 4; ++j) xv[b][j] = xs[b * nchunk + xs_slot<Q>(4 * c + j)];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          // one row at a time: without the fence the scheduler interleaves the four
+          // rows' expansions (64 more live registers) and the kernel spills
+          __builtin_amdgcn_sched_barrier(0);
+          float s[B];
+#pragma unroll
+          for (int b = 0; b < B; ++b) s[b] = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            unsigned int e[4];
+            w4_expand8(wv[r][j], p.code, e);
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) s[b] = dot2_bf16(e[i], xv[b][j][i], s[b]);
+          }
+#pragma unroll
+          for (int b = 0; b < B; ++b) acc[r][b] = fmaf(sc[r], s[b], acc[r][b]);
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          u32x4_t xv;
+          if constexpr (P == P_RMSNORM) xv = xs[b * nchunk + c];
+          else xv = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[r][b] = dot8_bf16(wv[r], xv, acc[r][b]);
+        }
       }
     };
     int c = c_begin + lane;
-    if constexpr (P == P_RMSNORM) {
-      if (ub == blockIdx.x) {  // the chunks requested ahead of the norm
+    if constexpr (STAGE) {
+      if (ub == blockIdx.x) {  // the chunks requested ahead of the prologue
 #pragma unroll
         for (int i = 0; i < PRE; ++i) {
-          if (c < c_end) consume(pre[i], c);
+          if (c < c_end) consume(pre[i], pre_sc[i], c);
           c += 64;
         }
       }
     }
-#pragma unroll 4
+    // bf16: 4 iterations (16 loads) in flight per lane; 4-bit: one iteration is already
+    // 2048 weights per row-quad and the expansion needs the registers
+#pragma unroll(Q ? 1 : 4)
     for (; c < c_end; c += 64) {
       u32x4_t wv[R];
+      float sc[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) wv[r] = load_stream16(wp[r] + c * 8);
-      consume(wv, c);
+      for (int r = 0; r < R; ++r) {
+        wv[r] = load_stream16(wp[r] + static_cast<size_t>(c) * 16);
+        if constexpr (Q) sc[r] = __builtin_nontemporal_load(sp[r] + (c >> 1));
+      }
+      consume(wv, sc, c);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -452,16 +527,23 @@ static int gemv_grid(int N, int ks) {
   return blocks < cap ? blocks : cap;
 }
 
-template <int P, int E, int KS>
+template <int P, int E, int KS, int Q>
 static void launch_bk(const GemvParams& p, int B, hipStream_t st) {
   const size_t part = ((GEMV_WAVES * R * B * 4 + 15) / 16) * 16;
-  const size_t smem = part + 64 + (P == P_RMSNORM ? static_cast<size_t>(B) * (p.K / 8) * 16 : 0);
-  dim3 g(gemv_grid(p.N, KS)), b(GEMV_WAVES * 64);
+  const size_t smem = part + 64 + ((P == P_RMSNORM || Q) ? static_cast<size_t>(B) * (p.K / 8) * 16 : 0);
+  // 4-bit blocks stage x for every projection and do a quarter of the streaming per unit:
+  // 1024 looping blocks (4 resident per CU) amortise that (1.92 -> 1.87 ms per 7B step)
+  static const int cap4 = [] { const char* e = getenv("EVGPT_W4_CAP"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();
+  const int full = gemv_grid(p.N, KS);
+  dim3 g(Q && full > cap4 ? cap4 : full), b(GEMV_WAVES * 64);
   switch (B) {
-    case 1: hipLaunchKernelGGL((gemv_kernel<1, P, E, KS>), g, b, smem, st, p); break;
-    case 2: hipLaunchKernelGGL((gemv_kernel<2, P, E, KS>), g, b, smem, st, p); break;
-    case 3: hipLaunchKernelGGL((gemv_kernel<3, P, E, KS>), g, b, smem, st, p); break;
-    case 4: hipLaunchKernelGGL((gemv_kernel<4, P, E, KS>), g, b, smem, st, p); break;
+    case 1: hipLaunchKernelGGL((gemv_kernel<1, P, E, KS, Q>), g, b, smem, st, p); break;
+    case 2: hipLaunchKernelGGL((gemv_kernel<2, P, E, KS, Q>), g, b, smem, st, p); break;
+    case 3: hipLaunchKernelGGL((gemv_kernel<3, P, E, KS, Q>), g, b, smem, st, p); break;
+    case 4:
+      // 4-bit weights keep 16 x registers per row and are routed to <= 3 rows by the caller
+      if constexpr (Q == 0) hipLaunchKernelGGL((gemv_kernel<4, P, E, KS, Q>), g, b, smem, st, p);
+      break;
     default: break;
   }
 }
@@ -469,12 +551,23 @@ static void launch_bk(const GemvParams& p, int B, hipStream_t st) {
 template <int P, int E>
 static void launch_b(const GemvParams& p, int B, hipStream_t st) {
   if constexpr (E == E_LOGITS) {
-    launch_bk<P, E, 1>(p, B, st);
+    launch_bk<P, E, 1, 0>(p, B, st);
+  } else if (p.absmax) {
+    // a 4-bit row is a quarter of the bytes, so half the waves per unit keep the per-wave
+    // work (and the share of a block's prologue) comparable; measured on the 7B decode
+    // step: 2.12 ms with the bf16 choice, 1.92 ms with half (EVGPT_W4_KS_SHIFT to tune)
+    static const int shift = [] { const char* e = getenv("EVGPT_W4_KS_SHIFT"); return e ? atoi(e) : 1; }();
+    int ks = pick_ks(p.N) >> shift;
+    switch (ks < 1 ? 1 : ks) {
+      case 1: launch_bk<P, E, 1, 1>(p, B, st); break;
+      case 2: launch_bk<P, E, 2, 1>(p, B, st); break;
+      default: launch_bk<P, E, 4, 1>(p, B, st); break;
+    }
   } else {
     switch (pick_ks(p.N)) {
-      case 1: launch_bk<P, E, 1>(p, B, st); break;
-      case 2: launch_bk<P, E, 2>(p, B, st); break;
-      default: launch_bk<P, E, 4>(p, B, st); break;
+      case 1: launch_bk<P, E, 1, 0>(p, B, st); break;
+      case 2: launch_bk<P, E, 2, 0>(p, B, st); break;
+      default: launch_bk<P, E, 4, 0>(p, B, st); break;
     }
   }
 }
@@ -483,10 +576,17 @@ int gemv_max_batch() { return 4; }
 
 int gemv_logits_grid(int N) { return gemv_grid(N, 1); }
 
+int gemv_w4_max_batch() { return 3; }
+
+static void set_w4(GemvParams& p, const W4Desc* w4) {
+  if (w4) { p.absmax = w4->absmax; p.code = w4->code; }
+}
+
 void launch_gemv(const bf16_t* W, const bf16_t* x, bf16_t* y, const bf16_t* bias,
                  const bf16_t* res, const bf16_t* norm_w, float eps, int act, int B, int N,
-                 int K, hipStream_t st) {
+                 int K, hipStream_t st, const W4Desc* w4) {
   GemvParams p{};
+  set_w4(p, w4);
   p.W = W; p.x = x; p.y = y; p.bias = bias; p.res = res; p.norm_w = norm_w; p.eps = eps;
   p.act = act; p.N = N; p.K = K;
   if (res) {
@@ -500,8 +600,9 @@ void launch_gemv(const bf16_t* W, const bf16_t* x, bf16_t* y, const bf16_t* bias
 
 void launch_gemv_swiglu(const bf16_t* W_gate_up, const bf16_t* x, bf16_t* y,
                         const bf16_t* norm_w, float eps, int B, int inter, int K,
-                        hipStream_t st) {
+                        hipStream_t st, const W4Desc* w4) {
   GemvParams p{};
+  set_w4(p, w4);
   p.W = W_gate_up; p.x = x; p.y = y; p.norm_w = norm_w; p.eps = eps; p.N = 2 * inter; p.K = K;
   if (norm_w) launch_b<P_RMSNORM, E_SWIGLU>(p, B, st);
   else launch_b<P_NONE, E_SWIGLU>(p, B, st);
@@ -511,8 +612,9 @@ void launch_gemv_qkv_rope(const bf16_t* W_qkv, const bf16_t* x, const bf16_t* no
                           bf16_t* q_out, bf16_t* k_cache, bf16_t* v_cache, const float* cos_tab,
                           const float* sin_tab, const int* pos, int B, int n_q_heads,
                           int n_kv_heads, int head_dim, int l_max, int K, hipStream_t st,
-                          int rows_one_seq) {
+                          int rows_one_seq, const W4Desc* w4) {
   GemvParams p{};
+  set_w4(p, w4);
   p.rows_one_seq = rows_one_seq;
   p.W = W_qkv; p.x = x; p.norm_w = norm_w; p.eps = eps; p.K = K;
   p.N = (n_q_heads + 2 * n_kv_heads) * head_dim;

@@ -504,5 +504,6 @@ class EventChatModel(nn.Module):
         """The serving engine bound to this model's weights (built on first use)."""
         if self._engine is None:
             from ..runtime.engine import GenerationEngine
-            self._engine = GenerationEngine(self, **kwargs)
+            # engine_defaults: set by eventgpt_amd.quant.apply_quant_args (4-bit weights)
+            self._engine = GenerationEngine(self, **{**getattr(self, "engine_defaults", {}), **kwargs})
         return self._engine

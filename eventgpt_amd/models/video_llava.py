@@ -134,7 +134,7 @@ class LlamaForCausalLM(nn.Module):
     def engine(self, **kw):
         if self._engine is None:
             from ..runtime.engine import GenerationEngine
-            self._engine = GenerationEngine(self, **kw)
+            self._engine = GenerationEngine(self, **{**getattr(self, "engine_defaults", {}), **kw})
         return self._engine
 
 

@@ -235,6 +235,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--chunk_size", type=int, default=1000)
     p.add_argument("--egpt_model_path", default=None)
     p.add_argument("--vl_model_path", default=None)
+    from ..quant import add_quant_args
+    add_quant_args(p)
     p.add_argument("--random_init", default=None, choices=["7b", "tiny"],
                    help="random weights of the named size instead of checkpoints")
     p.add_argument("--event_image_key", default="event_image")
@@ -247,6 +249,7 @@ def load_models(args):
     from ..data.tokenizer import ByteTokenizer, load_tokenizer
     from ..models import EventChatConfig, EventChatModel
     from ..models.video_llava import VideoLlavaConfig, VideoLlavaModel, VideoProcessor
+    from ..quant import apply_quant_args
     dev = args.device
     dtype = torch.bfloat16 if str(dev).startswith("cuda") else torch.float32
     if args.random_init:
@@ -257,9 +260,11 @@ def load_models(args):
             ecfg, vcfg = EventChatConfig.tiny(), VideoLlavaConfig.tiny()
         egpt = EventChatModel.from_config(ecfg, dtype, dev, seed=0)
         vl = VideoLlavaModel.from_config(vcfg, dtype, dev, seed=1)
+        apply_quant_args(args, egpt, vl)
         return egpt, tok, vl, VideoProcessor(vcfg, tok)
     egpt = EventChatModel.from_pretrained(args.egpt_model_path, dtype, device=dev)
     vl = VideoLlavaModel.from_pretrained(args.vl_model_path, dtype, device=dev)
+    apply_quant_args(args, egpt, vl)
     return (egpt, load_tokenizer(args.egpt_model_path), vl,
             VideoProcessor(vl.config, load_tokenizer(args.vl_model_path)))
 

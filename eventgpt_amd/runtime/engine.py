@@ -16,6 +16,13 @@ LLaMA-family decoder whose weights live in an ``EventChatModel``.
   * the whole step is captured once into a HIP graph and replayed per token;
     the host only polls the EOS flag every ``poll_every`` tokens.
 
+``weight_format="nf4"`` (or ``"fp4"``) keeps the four projection matrices of every
+layer as 4-bit codes + one fp32 scale per 64 weights (``eventgpt_amd.quant``): the
+decode GEMVs stream a quarter of the bytes and look the levels up in registers;
+passes with more rows expand one matrix at a time into a bf16 scratch and run the
+MFMA GEMM on it.  The LM head and the embedding stay bf16, as in the reference's
+bitsandbytes configuration (pipeline/feature_extraction/extract_hidden_states.py:117-122).
+
 Prefill runs the same weights through the MFMA GEMM and the fused causal
 attention kernel and appends to the same cache.  The reference's equivalent is
 HF ``generate`` / its hand-rolled loops with one host sync and several
@@ -42,6 +49,7 @@ class _Layer:
     norm2: torch.Tensor
     k_cache: torch.Tensor
     v_cache: torch.Tensor
+    q4: Optional[dict] = None     # name -> W4Weight when the engine runs 4-bit weights
 
 
 def _pad_rows(w: torch.Tensor, mult: int) -> torch.Tensor:
@@ -53,7 +61,8 @@ def _pad_rows(w: torch.Tensor, mult: int) -> torch.Tensor:
 
 class GenerationEngine:
     def __init__(self, model, max_len: int = 2560, max_batch: int = 1, nsplit: int = 16,
-                 use_graph: bool = True, max_new_tokens: int = 1024, poll_every: int = 16):
+                 use_graph: bool = True, max_new_tokens: int = 1024, poll_every: int = 16,
+                 weight_format: str = "bf16", release_bf16: bool = False):
         from ..ops import hip  # raises if the extension is missing
         self.raw = hip.raw
         cfg = model.config
@@ -83,10 +92,18 @@ class GenerationEngine:
         if self.H % 64 or self.I % 8:
             raise ValueError("hidden size must be a multiple of 64, intermediate of 8")
 
+        if weight_format not in ("bf16", "nf4", "fp4"):
+            raise ValueError(f"weight_format {weight_format!r}: bf16, nf4 or fp4")
+        self.weight_format = weight_format
+        self.w4 = weight_format != "bf16"
         self.tp_world, self.tp_rank, self.tp_group = 1, 0, None
         self._setup_parallel()
+        if self.w4 and self.tp_world > 1:
+            raise NotImplementedError("4-bit weights are implemented for the single-GPU engine only")
         self.layers: List[_Layer] = []
         self._pack_weights(model)
+        if self.w4:
+            self._quantize_layers(release_bf16)
         self.V = self.lm_head.shape[0]
         cos, sin = ops.rope_tables(max_len, self.D, cfg.rope_theta, dev)
         self.cos, self.sin = cos.contiguous(), sin.contiguous()
@@ -150,6 +167,46 @@ class GenerationEngine:
         self.lm_head = model.lm_head.weight.data
         self.embed = model.model.embed_tokens.weight.data
 
+    _W4_NAMES = ("w_qkv", "w_o", "w_gate_up", "w_down")
+
+    def _quantize_layers(self, release_bf16: bool) -> None:
+        """Quantise the packed projections of every layer (on the GPU, ~1 s for 7B) and
+        allocate one bf16 scratch per projection kind for the GEMM paths.  With
+        ``release_bf16`` the bf16 originals are dropped (the module path stops working;
+        the engine then holds 3.9 GB of weights for a 7B decoder instead of 13 GB)."""
+        from ..quant import quantize_weight
+        if self.H % 64 or self.I % 64 or (self.Hq * self.D) % 64:
+            raise ValueError("4-bit weights need every projection's input size to be a multiple of 64")
+        self._w4_scratch = {}
+        for l in self.layers:
+            l.q4 = {n: quantize_weight(getattr(l, n), self.weight_format) for n in self._W4_NAMES}
+            for n in self._W4_NAMES:
+                if n not in self._w4_scratch:
+                    self._w4_scratch[n] = torch.empty_like(getattr(l, n))
+        if release_bf16:
+            empty = torch.empty(0, dtype=torch.bfloat16, device=self.device)
+            for l, lyr in zip(self.layers, self.model.model.layers):
+                for n in self._W4_NAMES:
+                    setattr(l, n, None)
+                for lin in (lyr.self_attn.q_proj, lyr.self_attn.k_proj, lyr.self_attn.v_proj,
+                            lyr.self_attn.o_proj, lyr.mlp.gate_proj, lyr.mlp.up_proj, lyr.mlp.down_proj):
+                    lin.weight.data = empty
+            torch.cuda.empty_cache()
+
+    def _w(self, l: _Layer, name: str) -> torch.Tensor:
+        """The bf16 matrix a GEMM path multiplies by: the weight itself, or the 4-bit
+        weight expanded into this projection kind's scratch."""
+        if not self.w4:
+            return getattr(l, name)
+        return l.q4[name].dequantize(self._w4_scratch[name])
+
+    @property
+    def weight_bytes(self) -> int:
+        """Bytes of decoder-layer weights one decode step streams."""
+        if self.w4:
+            return sum(q.nbytes for l in self.layers for q in l.q4.values())
+        return sum(getattr(l, n).numel() * 2 for l in self.layers for n in self._W4_NAMES)
+
     # ------------------------------------------------------------------ state
     def reset(self) -> None:
         for t in (self.step, self.pos, self.done, self.cur_token):
@@ -200,7 +257,8 @@ class GenerationEngine:
     gemv_rows = 3
 
     def _gemv_rows_ok(self, rows: int) -> bool:
-        return 1 <= rows <= min(self.gemv_rows, int(self.raw.gemv_max_batch())) and self.tp_world == 1
+        cap = int(self.raw.gemv_w4_max_batch() if self.w4 else self.raw.gemv_max_batch())
+        return 1 <= rows <= min(self.gemv_rows, cap) and self.tp_world == 1
 
     def _forward_rows_gemv(self, embeds: torch.Tensor, batch: int, pos0: torch.Tensor) -> torch.Tensor:
         raw = self.raw
@@ -212,13 +270,36 @@ class GenerationEngine:
         h = torch.empty(S, self.I, dtype=torch.bfloat16, device=self.device)
         for l in self.layers:
             kc, vc = l.k_cache[batch:batch + 1], l.v_cache[batch:batch + 1]
-            raw.decode_qkv(x, l.norm1, l.w_qkv, q, kc, vc, self.cos, self.sin, pos0, self.eps,
-                           self.Hq, self.Hkv, self.D, True)
+            self._gemv_qkv(l, x, q, kc, vc, pos0, True)
             raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
-            raw.decode_gemv_residual(l.w_o, o.view(S, self.Hq * self.D), x)
-            raw.decode_mlp_up(l.w_gate_up, x, l.norm2, self.eps, h)
-            raw.decode_gemv_residual(l.w_down, h, x)
+            self._gemv_residual(l, "w_o", o.view(S, self.Hq * self.D), x)
+            self._gemv_mlp_up(l, x, h)
+            self._gemv_residual(l, "w_down", h, x)
         return x.view(1, S, self.H)
+
+    # the four weight-streaming launches of a layer, in either weight format
+    def _gemv_qkv(self, l, x, q, kc, vc, pos, one_seq: bool) -> None:
+        if self.w4:
+            w = l.q4["w_qkv"]
+            self.raw.decode_qkv_w4(x, l.norm1, w.packed, w.absmax, w.code, q, kc, vc, self.cos, self.sin,
+                                   pos, self.eps, self.Hq, self.Hkv, self.D, one_seq)
+        else:
+            self.raw.decode_qkv(x, l.norm1, l.w_qkv, q, kc, vc, self.cos, self.sin, pos, self.eps,
+                                self.Hq, self.Hkv, self.D, one_seq)
+
+    def _gemv_residual(self, l, name: str, xin, y) -> None:
+        if self.w4:
+            w = l.q4[name]
+            self.raw.decode_gemv_residual_w4(w.packed, w.absmax, w.code, xin, y)
+        else:
+            self.raw.decode_gemv_residual(getattr(l, name), xin, y)
+
+    def _gemv_mlp_up(self, l, x, h) -> None:
+        if self.w4:
+            w = l.q4["w_gate_up"]
+            self.raw.decode_mlp_up_w4(w.packed, w.absmax, w.code, x, l.norm2, self.eps, h)
+        else:
+            self.raw.decode_mlp_up(l.w_gate_up, x, l.norm2, self.eps, h)
 
     # Row counts up to this take the few-row path: projections stop at their fp32
     # split-K slabs and the op that follows (RoPE + cache append, residual + next
@@ -240,14 +321,14 @@ class GenerationEngine:
         n = len(self.layers)
         for i, l in enumerate(self.layers):
             kc, vc = l.k_cache[batch:batch + 1], l.v_cache[batch:batch + 1]
-            raw.reduce_rope_kv(raw.linear_partial(xn, l.w_qkv), q, kc, vc, self.cos, self.sin, pos0,
+            raw.reduce_rope_kv(raw.linear_partial(xn, self._w(l, "w_qkv")), q, kc, vc, self.cos, self.sin, pos0,
                                1, S, self.Hq, self.Hkv, self.D)
             raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
-            x, xn = raw.reduce_residual_norm(raw.linear_partial(o.view(S, self.Hq * self.D), l.w_o),
+            x, xn = raw.reduce_residual_norm(raw.linear_partial(o.view(S, self.Hq * self.D), self._w(l, "w_o")),
                                              x, l.norm2, self.eps, None)
-            h = raw.reduce_swiglu(raw.linear_partial(xn, l.w_gate_up))
+            h = raw.reduce_swiglu(raw.linear_partial(xn, self._w(l, "w_gate_up")))
             nxt = self.layers[i + 1].norm1 if i + 1 < n else None
-            x, xn = raw.reduce_residual_norm(raw.linear_partial(h, l.w_down), x, nxt, self.eps, None)
+            x, xn = raw.reduce_residual_norm(raw.linear_partial(h, self._w(l, "w_down")), x, nxt, self.eps, None)
         return x.view(1, S, self.H)
 
     def _forward_rows(self, embeds: torch.Tensor, batch: int, pos0: torch.Tensor) -> torch.Tensor:
@@ -268,13 +349,13 @@ class GenerationEngine:
         for l in self.layers:
             kc, vc = l.k_cache[batch:batch + 1], l.v_cache[batch:batch + 1]
             xn = raw.rmsnorm(x, l.norm1, self.eps)
-            qkv = raw.linear(xn, l.w_qkv, None, None, 0, False)
+            qkv = raw.linear(xn, self._w(l, "w_qkv"), None, None, 0, False)
             raw.prefill_rope_kv(qkv, q, kc, vc, self.cos, self.sin, pos0, self.Hq, self.Hkv, self.D)
             raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
-            x = raw.linear(o.view(1, S, self.Hq * self.D), l.w_o, None, x, 0, False)
+            x = raw.linear(o.view(1, S, self.Hq * self.D), self._w(l, "w_o"), None, x, 0, False)
             xn = raw.rmsnorm(x, l.norm2, self.eps)
-            gu = raw.linear(xn, l.w_gate_up, None, None, 0, False)
-            x = raw.linear(raw.swiglu(gu), l.w_down, None, x, 0, False)
+            gu = raw.linear(xn, self._w(l, "w_gate_up"), None, None, 0, False)
+            x = raw.linear(raw.swiglu(gu), self._w(l, "w_down"), None, x, 0, False)
         return x
 
     # ----------------------------------------------------- speculative verify
@@ -332,14 +413,15 @@ class GenerationEngine:
     # ------------------------------------------------------------ decode step
     def _layers_step(self) -> None:
         raw = self.raw
+        if self.w4 and self.B > int(raw.gemv_w4_max_batch()):
+            raise RuntimeError(f"4-bit decode steps take up to {int(raw.gemv_w4_max_batch())} sequences")
         for l in self.layers:
-            raw.decode_qkv(self.x, l.norm1, l.w_qkv, self.q, l.k_cache, l.v_cache, self.cos,
-                           self.sin, self.pos, self.eps, self.Hq, self.Hkv, self.D)
+            self._gemv_qkv(l, self.x, self.q, l.k_cache, l.v_cache, self.pos, False)
             raw.decode_attn(self.q, l.k_cache, l.v_cache, self.attn, self.part_o, self.part_ml,
                             self.pos, self.nsplit, self.scale)
-            raw.decode_gemv_residual(l.w_o, self.attn, self.x)
-            raw.decode_mlp_up(l.w_gate_up, self.x, l.norm2, self.eps, self.h)
-            raw.decode_gemv_residual(l.w_down, self.h, self.x)
+            self._gemv_residual(l, "w_o", self.attn, self.x)
+            self._gemv_mlp_up(l, self.x, self.h)
+            self._gemv_residual(l, "w_down", self.h, self.x)
 
     def _logits_and_commit(self, greedy: bool, want_logits: bool = False) -> None:
         raw = self.raw
