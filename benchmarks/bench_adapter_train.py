@@ -9,7 +9,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from eventgpt_amd.align.store import ChunkedHiddenStateWriter  # noqa: E402
 from eventgpt_amd.align import trainer as TR  # noqa: E402
 

@@ -4,7 +4,7 @@ the GEMM + fused slab consumer, and the single-row GEMV, as GB/s of weight bytes
 import sys
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from eventgpt_amd.ops import hip  # noqa: E402
 
 raw = hip.raw

@@ -6,7 +6,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from eventgpt_amd.ops import hip  # noqa: E402
 
 raw = hip.raw

@@ -7,7 +7,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from eventgpt_amd.models import EventChatConfig, EventChatModel  # noqa: E402
 from eventgpt_amd.parallel.tp import TensorParallelEngine  # noqa: E402
 from eventgpt_amd.runtime.batcher import ContinuousBatcher  # noqa: E402

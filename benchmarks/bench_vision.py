@@ -5,7 +5,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from eventgpt_amd.models import EventChatConfig, EventChatModel  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1

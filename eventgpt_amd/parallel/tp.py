@@ -205,6 +205,9 @@ class TensorParallelEngine(GenerationEngine):
         if (group is not None and dist.is_initialized() and dist.get_world_size(group) > 1
                 and dist.get_backend(group) == "gloo"):
             kw["use_graph"] = False     # gloo collectives go through host copies: nothing to capture
+        if kw.get("weight_format", "bf16") != "bf16":
+            raise NotImplementedError("the batched / tensor-parallel engine runs bf16 weights; 4-bit weights "
+                                      "are a GenerationEngine (single stream, <= 3 rows) format")
         super().__init__(model, max_len=max_len, max_batch=max_batch, **kw)
         if self.tp_world > 1:   # samplers read the gathered, full-vocabulary rows
             self.logits = torch.zeros(self.B, self.v_total, dtype=torch.float32, device=self.device)
