@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--prompt-len", type=int, default=636,
                     help="multimodal prompt length (636 = 1 event frame: 578 event + 58 text)")
     ap.add_argument("--frames", type=int, default=1)
+    ap.add_argument("--max-len", type=int, default=2048, help="KV-cache capacity per stream")
     ap.add_argument("--parallelism", choices=["dp", "tp"], default="dp")
     ap.add_argument("--model", choices=["7b", "small"], default="7b")
     ap.add_argument("--no-graph", action="store_true")
@@ -91,11 +92,11 @@ def main():
     if tp or args.batch > 1:
         from eventgpt_amd.parallel.tp import TensorParallelEngine
         ekw["max_batch"] = args.batch
-        engine = TensorParallelEngine(model, dist.group.WORLD if tp else None, max_len=2048,
+        engine = TensorParallelEngine(model, dist.group.WORLD if tp else None, max_len=args.max_len,
                                       max_new_tokens=args.steps + args.warmup + 8,
                                       use_graph=not args.no_graph, **ekw)
     else:
-        engine = model.engine(max_len=2048, max_new_tokens=args.steps + args.warmup + 8,
+        engine = model.engine(max_len=args.max_len, max_new_tokens=args.steps + args.warmup + 8,
                               use_graph=not args.no_graph, **ekw)
 
     def sync_all():

@@ -10,11 +10,15 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from eventgpt_amd.ops import hip  # noqa: E402
 
 raw = hip.raw
+ONLY = sys.argv[1] if len(sys.argv) > 1 else None   # substring filter on the label
 SHAPES = [  # (M, N, K, label)
     (636, 12288, 4096, "llm qkv"), (636, 22016, 4096, "llm gate_up"), (636, 4096, 4096, "llm o_proj"),
     (636, 4096, 11008, "llm down"), (577, 3072, 1024, "vit qkv"), (577, 1024, 1024, "vit out"),
     (577, 4096, 1024, "vit fc1"), (577, 1024, 4096, "vit fc2"), (577, 4096, 4096, "projector"),
     (2885, 3072, 1024, "vit qkv T=5"), (2885, 1024, 4096, "vit fc2 T=5"), (22, 32064, 4096, "verify lm_head"),
+    (2115, 12288, 4096, "verifier qkv"), (2115, 22016, 4096, "verifier gate_up"), (2115, 4096, 11008, "verifier down"),
+    (4643, 12288, 4096, "8f qkv"), (4643, 22016, 4096, "8f gate_up"), (4643, 4096, 4096, "8f o_proj"),
+    (4643, 4096, 11008, "8f down"), (20352, 4096, 4096, "bs32 prefill o_proj"),
     (32, 4096, 4096, "bs32 o_proj"), (3200, 4096, 256, "adapter up"), (3200, 256, 4096, "adapter down"),
 ]
 CFGS = {0: "128x128s2", 1: "64x128s3", 2: "64x64s4", 3: "32x64s4", 4: "32x128s4"}
@@ -39,6 +43,8 @@ def main():
     print(f"{'shape':28s} {'auto':>9s} " + " ".join(f"{v:>10s}" for v in CFGS.values())
           + " " + " ".join(f"{'sk' + str(k):>6s}" for k in (2, 4, 8)) + f" {'hipBLASLt':>10s}")
     for M, N, K, label in SHAPES:
+        if ONLY and ONLY not in label:
+            continue
         x = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
         fl = 2.0 * M * N * K
