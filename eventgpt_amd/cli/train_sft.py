@@ -134,14 +134,23 @@ class SFTTrainer:
         self.step = 0
         os.makedirs(output_dir, exist_ok=True)
 
-    # one (sample) -> loss; None if the sample has no usable event data / answer
-    def sample_loss(self, sample: Dict) -> Optional[torch.Tensor]:
-        m = self.model
+    def prepare_sample(self, sample: Dict) -> Optional[Dict]:
+        """Host-only half of a sample (image decode / rasterisation, tokenisation); the
+        training loop runs it one sample ahead on a worker thread."""
         ans = answer_of(sample)
         imgs = load_event_rasters(self.ds, sample, self.num_frames, self.key)
         if not ans or not imgs:
             return None
         ids, labels = build_example(self.tok, self.ds.question(sample), ans, max_len=self.max_len)
+        return {"imgs": imgs, "ids": ids, "labels": labels}
+
+    # one (sample) -> loss; None if the sample has no usable event data / answer
+    def sample_loss(self, sample: Dict, prepared: Optional[Dict] = None) -> Optional[torch.Tensor]:
+        m = self.model
+        prepared = prepared if prepared is not None else self.prepare_sample(sample)
+        if prepared is None:
+            return None
+        imgs, ids, labels = prepared["imgs"], prepared["ids"], prepared["labels"]
         size = m.get_visual_tower().event_processor.size
         frames = list(preprocess_frames(imgs, m.device, size, m.dtype))
         out = m(input_ids=ids[None].to(m.device), labels=labels[None].to(m.device), event_tensors=[frames],
@@ -204,14 +213,19 @@ class SFTTrainer:
         gen = torch.Generator().manual_seed(seed)
         for _ in range(start_epoch):                     # keep the shuffles of a resumed run aligned
             torch.randperm(len(mine), generator=gen)
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1)
         for epoch in range(start_epoch, num_epochs):
             self.model.train()
             order = torch.randperm(len(mine), generator=gen).tolist()
             run, n_run, micro, skipped = 0.0, 0, 0, 0
             t_epoch, steps0 = time.perf_counter(), self.step
             self.opt.zero_grad()
+            fut = pool.submit(self.prepare_sample, self.ds[mine[order[0]]]) if order else None
             for j, oi in enumerate(order):
-                loss = self.sample_loss(self.ds[mine[oi]])
+                prepared = fut.result()
+                fut = pool.submit(self.prepare_sample, self.ds[mine[order[j + 1]]]) if j + 1 < len(order) else None
+                loss = self.sample_loss(self.ds[mine[oi]], prepared) if prepared is not None else None
                 if loss is None:
                     # every rank must take the same number of optimizer steps: a rank that
                     # cannot use a sample contributes a zero gradient for it
@@ -238,6 +252,7 @@ class SFTTrainer:
                                  "s_per_step": dt / max(self.step - steps0, 1)})
             if save_every_epoch:
                 self.save_state(epoch)
+        pool.shutdown(wait=True)
         paths = self.save_outputs()
         if info.is_main:
             with open(os.path.join(self.out, "history.json"), "w") as f:

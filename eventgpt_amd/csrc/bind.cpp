@@ -8,6 +8,7 @@
 //     capture into a hipGraph (no allocation, no host sync).
 // Host-side shape checks live here so a kernel is never launched on operands
 // that do not match what its indexing assumes.
+#include <cmath>
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
@@ -358,6 +359,56 @@ void decode_qkv(const Tensor& x, const Tensor& norm_w, const Tensor& w_qkv, cons
                               bptr_mut(k_cache), bptr_mut(v_cache), cos.data_ptr<float>(),
                               sin.data_ptr<float>(), pos.data_ptr<int>(), (int)B, (int)Hq, (int)Hkv,
                               (int)D, (int)k_cache.size(2), (int)K, cur_stream(), one_seq ? 1 : 0);
+}
+
+// dx (and, when dw is given, dw += the weight gradient in fp32) of y = rmsnorm(x) * w
+Tensor rmsnorm_bwd(const Tensor& x, const Tensor& w, const Tensor& g, double eps,
+                   const c10::optional<Tensor>& dw) {
+  check_bf16(x, "x"); check_bf16(w, "weight"); check_bf16(g, "grad");
+  const int64_t H = x.size(-1), rows = x.numel() / H;
+  TORCH_CHECK(H % 8 == 0 && H <= 8192 && w.numel() == H && g.numel() == x.numel(),
+              "rmsnorm_bwd: hidden size must be a multiple of 8 up to 8192");
+  Tensor dx = at::empty_like(x);
+  float* dwp = nullptr;
+  if (dw.has_value()) { check_f32(*dw, "dw"); TORCH_CHECK(dw->numel() == H); dwp = dw->data_ptr<float>(); }
+  evgpt::launch_rmsnorm_bwd(bptr(x), bptr(w), bptr(g), bptr_mut(dx), dwp, (int)rows, (int)H, (float)eps,
+                            cur_stream());
+  return dx;
+}
+
+Tensor swiglu_bwd(const Tensor& gate_up, const Tensor& gh) {
+  check_bf16(gate_up, "gate_up"); check_bf16(gh, "grad");
+  const int64_t I2 = gate_up.size(-1), M = gate_up.numel() / I2;
+  TORCH_CHECK(I2 % 16 == 0 && gh.numel() == M * (I2 / 2), "swiglu_bwd: shapes");
+  Tensor dgu = at::empty_like(gate_up);
+  evgpt::launch_swiglu_bwd(bptr(gate_up), bptr(gh), bptr_mut(dgu), M, (int)(I2 / 2), cur_stream());
+  return dgu;
+}
+
+// One optimizer shard: grad/param_out in the parameters' storage type (bf16 or fp32), fp32
+// master weights and moments, all of the same length; updates master, moments and param_out.
+void fused_adamw(const Tensor& grad, const Tensor& master, const Tensor& exp_avg, const Tensor& exp_avg_sq,
+                 const Tensor& param_out, double lr, double beta1, double beta2, double eps,
+                 double weight_decay, int64_t step, double clip) {
+  check_f32(master, "master"); check_f32(exp_avg, "exp_avg"); check_f32(exp_avg_sq, "exp_avg_sq");
+  const int64_t n = master.numel();
+  TORCH_CHECK(grad.is_cuda() && grad.is_contiguous() && param_out.is_cuda() && param_out.is_contiguous() &&
+              grad.numel() == n && param_out.numel() == n && exp_avg.numel() == n && exp_avg_sq.numel() == n,
+              "fused_adamw: all tensors are contiguous device tensors of one length");
+  TORCH_CHECK(grad.scalar_type() == param_out.scalar_type() && step >= 1, "fused_adamw: dtype/step");
+  evgpt::AdamWArgs a;
+  a.clip = (float)clip; a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps;
+  a.decay = (float)(1.0 - lr * weight_decay);
+  a.step_size = (float)(lr / (1.0 - std::pow(beta1, (double)step)));
+  a.inv_sqrt_bc2 = (float)(1.0 / std::sqrt(1.0 - std::pow(beta2, (double)step)));
+  if (grad.scalar_type() == at::kBFloat16)
+    evgpt::launch_fused_adamw_bf16(bptr(grad), master.data_ptr<float>(), exp_avg.data_ptr<float>(),
+                                   exp_avg_sq.data_ptr<float>(), bptr_mut(param_out), n, a, cur_stream());
+  else if (grad.scalar_type() == at::kFloat)
+    evgpt::launch_fused_adamw_f32(grad.data_ptr<float>(), master.data_ptr<float>(), exp_avg.data_ptr<float>(),
+                                  exp_avg_sq.data_ptr<float>(), param_out.data_ptr<float>(), n, a, cur_stream());
+  else
+    TORCH_CHECK(false, "fused_adamw: bfloat16 or float32 parameters");
 }
 
 // ---- 4-bit codebook weights: `packed` uint8 [N, K/2], `absmax` fp32 [N, K/64], `code` a
@@ -734,6 +785,9 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("decode_qkv(Tensor x, Tensor norm_w, Tensor w_qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos, float eps, int Hq, int Hkv, int D, bool one_seq=False) -> ()", &decode_qkv);
   m.def("decode_attn(Tensor q, Tensor k_cache, Tensor v_cache, Tensor(a!) out, Tensor(b!) part_o, Tensor(c!) part_ml, Tensor pos, int nsplit, float scale) -> ()", &decode_attn);
   m.def("decode_gemv_residual(Tensor w, Tensor xin, Tensor(a!) y) -> ()", &decode_gemv_residual);
+  m.def("rmsnorm_bwd(Tensor x, Tensor weight, Tensor grad, float eps, Tensor(a!)? dw=None) -> Tensor", &rmsnorm_bwd);
+  m.def("swiglu_bwd(Tensor gate_up, Tensor grad) -> Tensor", &swiglu_bwd);
+  m.def("fused_adamw(Tensor grad, Tensor(a!) master, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor(d!) param_out, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float clip) -> ()", &fused_adamw);
   m.def("w4_dequant(Tensor packed, Tensor absmax, Tensor code, Tensor(a!)? out=None) -> Tensor", &w4_dequant);
   m.def("gemv_w4_max_batch() -> int", []() { return (int64_t)evgpt::gemv_w4_max_batch(); });
   m.def("decode_qkv_w4(Tensor x, Tensor norm_w, Tensor packed, Tensor absmax, Tensor code, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos, float eps, int Hq, int Hkv, int D, bool one_seq=False) -> ()", &decode_qkv_w4);

@@ -33,6 +33,18 @@ void launch_gemv_logits(const bf16_t* W, const bf16_t* x, const bf16_t* norm_w, 
                         float* logits, float* part_val, int* part_idx, int B, int N, int K,
                         hipStream_t st);
 
+// ---- train_bwd.hip
+void launch_rmsnorm_bwd(const bf16_t* x, const bf16_t* w, const bf16_t* g, bf16_t* dx, float* dw, int rows,
+                        int H, float eps, hipStream_t st);
+void launch_swiglu_bwd(const bf16_t* gate_up, const bf16_t* gh, bf16_t* dgu, long long M, int I, hipStream_t st);
+
+// ---- optim.hip
+struct AdamWArgs { float clip, beta1, beta2, eps, decay /* 1 - lr*wd */, step_size /* lr / bc1 */, inv_sqrt_bc2; };
+void launch_fused_adamw_bf16(const bf16_t* grad, float* master, float* m, float* v, bf16_t* out, long long n,
+                             const AdamWArgs& a, hipStream_t st);
+void launch_fused_adamw_f32(const float* grad, float* master, float* m, float* v, float* out, long long n,
+                            const AdamWArgs& a, hipStream_t st);
+
 // ---- gemm.hip
 int gemm_argmax_partials(int M, int N);
 void gemm_force_config(int cfg);  // -1 = automatic; for tuning runs

@@ -7,6 +7,12 @@ means re-materialising each weight matrix in fp32 on every call).  A call on GPU
 that needs autograd comes here instead: bf16 GEMMs with fp32 accumulation through
 ``F.linear`` (hipBLASLt), ``F.scaled_dot_product_attention``, fp32 statistics only on the
 activations of the norms.  Semantics match the oracle; rounding is that of bf16 training.
+
+RMSNorm, RoPE and SwiGLU on bf16 tensors are ``autograd.Function``s over the HIP kernels:
+the inference kernel in forward and one backward kernel each (``csrc/kernels/train_bwd.hip``;
+RoPE's backward is the forward kernel with the angle negated).  Written as eager tensor
+expressions they are 8-12 launches per call, ~2 000 per 7B forward, and the step is bound by
+the host's launch rate (87 ms forward for ~840 tokens against 13 ms of kernel time).
 """
 from __future__ import annotations
 
@@ -19,7 +25,69 @@ import torch.nn.functional as F
 from .reference import _ACTS
 
 
+def _fused(*tensors) -> bool:
+    """bf16 device tensors and the HIP extension at hand: take the fused Functions."""
+    return all(t is None or (t.is_cuda and t.dtype == torch.bfloat16) for t in tensors) and _raw() is not None
+
+
+_RAW = []
+
+
+def _raw():
+    if not _RAW:
+        try:
+            from . import hip
+            _RAW.append(hip.raw)
+        except Exception:          # extension not built: eager expressions below
+            _RAW.append(None)
+    return _RAW[0]
+
+
+class _RMSNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, eps):
+        xc = x.contiguous()
+        ctx.save_for_backward(xc, weight)
+        ctx.eps = eps
+        return _raw().rmsnorm(xc, weight.contiguous(), eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        dw = torch.zeros(w.numel(), dtype=torch.float32, device=w.device) if ctx.needs_input_grad[1] else None
+        dx = _raw().rmsnorm_bwd(x, w.contiguous(), g.contiguous(), ctx.eps, dw)
+        return dx, (None if dw is None else dw.to(w.dtype).view_as(w)), None
+
+
+class _Rope(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, positions, cos, sin):
+        pos = positions.to(torch.long).contiguous()
+        ctx.save_for_backward(pos, cos, sin)
+        return _raw().rope(x.contiguous(), pos, cos, sin)
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, cos, sin = ctx.saved_tensors
+        return _raw().rope(g.contiguous(), pos, cos, -sin), None, None, None   # rotate back by the same angle
+
+
+class _SwiGLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gate_up):
+        gu = gate_up.contiguous()
+        ctx.save_for_backward(gu)
+        return _raw().swiglu(gu)
+
+    @staticmethod
+    def backward(ctx, g):
+        (gu,) = ctx.saved_tensors
+        return _raw().swiglu_bwd(gu, g.contiguous())
+
+
 def rmsnorm(x, weight, eps: float = 1e-6):
+    if _fused(x, weight) and x.shape[-1] % 8 == 0 and x.shape[-1] <= 8192:
+        return _RMSNorm.apply(x, weight, eps)
     xf = x.float()
     y = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype)
     return y * weight.to(x.dtype)
@@ -41,11 +109,16 @@ def linear(x, weight, bias=None, act: Optional[str] = None, residual=None):
 
 
 def swiglu(gate_up):
+    if _fused(gate_up) and gate_up.shape[-1] % 16 == 0:
+        return _SwiGLU.apply(gate_up)
     g, u = gate_up.chunk(2, dim=-1)
     return F.silu(g) * u
 
 
 def apply_rope(x, positions, cos, sin):
+    if (_fused(x) and x.dim() == 4 and x.shape[-1] % 16 == 0 and cos.dtype == torch.float32
+            and positions.numel() == x.shape[0] * x.shape[1]):
+        return _Rope.apply(x, positions, cos, sin)
     d2 = x.shape[-1] // 2
     c = cos[positions].unsqueeze(2).to(x.dtype)
     s = sin[positions].unsqueeze(2).to(x.dtype)

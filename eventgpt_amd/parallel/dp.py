@@ -50,7 +50,11 @@ class _Bucket:
         self.master = self.flat_param[self.shard_slice].float().clone()
         self.exp_avg = torch.zeros_like(self.master)
         self.exp_avg_sq = torch.zeros_like(self.master)
-        self.grad_shard = torch.zeros(self.shard_len, dtype=p0.dtype, device=p0.device)
+        # the averaged gradient of this rank's shard; with one rank that is the gradient itself
+        self.grad_shard = (self.flat_grad[self.shard_slice] if world == 1
+                           else torch.zeros(self.shard_len, dtype=p0.dtype, device=p0.device))
+        # staging for the refreshed shard when it has to be all-gathered (world > 1)
+        self.new_shard = torch.empty_like(self.grad_shard) if world > 1 else None
         self.pending = 0
         self.work = None
 
@@ -108,9 +112,8 @@ class ShardedAdamW:
             self._launch_reduce(b)
 
     def _launch_reduce(self, b: _Bucket) -> None:
-        if not self.distributed:
-            b.grad_shard.copy_(b.flat_grad[b.shard_slice])
-            return
+        if not self.distributed or self.world == 1:
+            return      # grad_shard aliases the flat gradient
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
@@ -126,7 +129,8 @@ class ShardedAdamW:
             if self.overlap:
                 if b.work is None:        # a parameter received no gradient this step
                     self._launch_reduce(b)
-                b.work.wait()
+                if b.work is not None:    # (a one-rank group has nothing in flight)
+                    b.work.wait()
             else:
                 self._launch_reduce(b)
         if self.comm_stream is not None:
@@ -141,7 +145,7 @@ class ShardedAdamW:
     def global_grad_norm(self) -> float:
         sq = torch.zeros((), dtype=torch.float32, device=self.buckets[0].grad_shard.device)
         for b in self.buckets:
-            sq += b.grad_shard.float().pow(2).sum()
+            sq += torch.linalg.vector_norm(b.grad_shard, dtype=torch.float32).square()
         if self.distributed:
             if dist.get_backend(self.group) == "gloo" and sq.is_cuda:
                 host = sq.cpu()
@@ -166,6 +170,15 @@ class ShardedAdamW:
         bc1 = 1 - b1 ** self.step_count
         bc2 = 1 - b2 ** self.step_count
         for b in self.buckets:
+            if b.master.is_cuda and b.flat_param.dtype in (torch.bfloat16, torch.float32):
+                # one pass over the shard (csrc/kernels/optim.hip) instead of ten launches
+                from ..ops import hip
+                new_shard = b.flat_param[b.shard_slice] if not self.distributed else b.new_shard
+                hip.raw.fused_adamw(b.grad_shard, b.master, b.exp_avg, b.exp_avg_sq, new_shard, lr, b1, b2,
+                                    self.eps, self.weight_decay, self.step_count, clip)
+                if self.distributed:
+                    dist.all_gather_into_tensor(b.flat_param, new_shard, group=self.group)
+                continue
             g = b.grad_shard.float() * clip
             b.master.mul_(1 - lr * self.weight_decay)
             b.exp_avg.mul_(b1).add_(g, alpha=1 - b1)

@@ -67,10 +67,11 @@ def test_preprocess_frames_device_dispatch(dev):
     c = eo.preprocess_frames(frames, "cpu", 56)
     assert g.is_cuda and g.shape == (4, 3, 56, 56) and g.dtype == torch.bfloat16
     assert torch.equal(g.cpu(), c)
-    # unequal sizes fall back to the host path, still on the requested device
+    # unequal sizes (per-slice canvases) run the kernel frame by frame: same pixels as the host path
     mixed = frames[:2] + [rng.integers(0, 256, (100, 90, 3), dtype=np.uint8)]
     m = eo.preprocess_frames(mixed, dev, 56)
     assert m.is_cuda and m.shape == (3, 3, 56, 56)
+    assert torch.equal(m.cpu(), eo.preprocess_frames(mixed, "cpu", 56))
     from eventgpt_amd.data.tokenizer import ByteTokenizer
     from eventgpt_amd.models.video_llava import VideoLlavaConfig, VideoProcessor
     cfg = VideoLlavaConfig.tiny()
