@@ -19,8 +19,9 @@ LLaMA-family decoder whose weights live in an ``EventChatModel``.
 ``weight_format="nf4"`` (or ``"fp4"``) keeps the four projection matrices of every
 layer as 4-bit codes + one fp32 scale per 64 weights (``eventgpt_amd.quant``): the
 decode GEMVs stream a quarter of the bytes and look the levels up in registers;
-passes with more rows expand one matrix at a time into a bf16 scratch and run the
-MFMA GEMM on it.  The LM head and the embedding stay bf16, as in the reference's
+passes with more rows run the MFMA GEMM on the dequantised matrix — kept in HBM in
+place of the original bf16 weights (so the module path computes the same quantised
+model), or, with ``release_bf16``, expanded one matrix at a time into a bf16 scratch.  The LM head and the embedding stay bf16, as in the reference's
 bitsandbytes configuration (pipeline/feature_extraction/extract_hidden_states.py:117-122).
 
 Prefill runs the same weights through the MFMA GEMM and the fused causal
@@ -170,19 +171,28 @@ class GenerationEngine:
     _W4_NAMES = ("w_qkv", "w_o", "w_gate_up", "w_down")
 
     def _quantize_layers(self, release_bf16: bool) -> None:
-        """Quantise the packed projections of every layer (on the GPU, ~1 s for 7B) and
-        allocate one bf16 scratch per projection kind for the GEMM paths.  With
-        ``release_bf16`` the bf16 originals are dropped (the module path stops working;
-        the engine then holds 3.9 GB of weights for a 7B decoder instead of 13 GB)."""
+        """Quantise the packed projections of every layer (on the GPU, ~1 s for 7B).
+
+        By default the bf16 weights are then overwritten IN PLACE by their dequantised
+        values: multi-row passes (prefill, long verifies) run at bf16-GEMM speed on exactly
+        the quantised model, and the module path (whose parameters are views of the same
+        storage) computes that model too.  With ``release_bf16`` the bf16 copies are dropped
+        instead (the module path stops working; the engine then holds 3.9 GB of weights for a
+        7B decoder instead of 13 GB) and multi-row passes expand one matrix at a time into a
+        scratch buffer per projection kind."""
         from ..quant import quantize_weight
         if self.H % 64 or self.I % 64 or (self.Hq * self.D) % 64:
             raise ValueError("4-bit weights need every projection's input size to be a multiple of 64")
         self._w4_scratch = {}
+        self._w4_release = bool(release_bf16)
         for l in self.layers:
             l.q4 = {n: quantize_weight(getattr(l, n), self.weight_format) for n in self._W4_NAMES}
             for n in self._W4_NAMES:
-                if n not in self._w4_scratch:
-                    self._w4_scratch[n] = torch.empty_like(getattr(l, n))
+                if release_bf16:
+                    if n not in self._w4_scratch:
+                        self._w4_scratch[n] = torch.empty_like(getattr(l, n))
+                else:
+                    l.q4[n].dequantize(getattr(l, n))
         if release_bf16:
             empty = torch.empty(0, dtype=torch.bfloat16, device=self.device)
             for l, lyr in zip(self.layers, self.model.model.layers):
@@ -196,7 +206,7 @@ class GenerationEngine:
     def _w(self, l: _Layer, name: str) -> torch.Tensor:
         """The bf16 matrix a GEMM path multiplies by: the weight itself, or the 4-bit
         weight expanded into this projection kind's scratch."""
-        if not self.w4:
+        if not self.w4 or not self._w4_release:
             return getattr(l, name)
         return l.q4[name].dequantize(self._w4_scratch[name])
 

@@ -193,6 +193,13 @@ def test_engine_w4_generate_graph_equals_eager_and_verify_paths():
     # replays after eager work in between give the same tokens again
     _ = ee.generate(emb, 5, eos_token_id=-1)
     assert torch.equal(eg.generate(emb, 24, eos_token_id=-1), te)
+    # the memory-lean mode (bf16 weights dropped, matrices expanded on the fly) gives the same tokens
+    m2 = EventChatModel.from_config(cfg, torch.bfloat16, _dev(), seed=4)
+    er = GenerationEngine(m2, max_len=128, max_new_tokens=40, weight_format="nf4", release_bf16=True)
+    assert er.layers[0].w_qkv is None and torch.equal(er.generate(emb, 24, eos_token_id=-1), te)
+    # by default the module path computes the same quantised model (its weights were rewritten in place)
+    w_mod = m.model.layers[0].self_attn.q_proj.weight.data
+    assert torch.equal(w_mod, eg.layers[0].q4["w_qkv"].dequantize()[: w_mod.shape[0]])
     # speculative verify: drafting the engine's own continuation is fully accepted, both on the
     # GEMV path (2 drafts -> 3 rows) and on the dequantise + GEMM path (6 drafts -> 7 rows)
     for G in (2, 6):
