@@ -162,11 +162,61 @@ def load_hidden_states(path: str) -> dict:
 
 # ------------------------------------------------------------------- batching
 def make_batch(egpt: torch.Tensor, vl: torch.Tensor, seq_lens: torch.Tensor) -> Dict[str, torch.Tensor]:
-    """Trim to the batch's longest sequence and build the validity mask."""
+    """Trim to the batch's longest sequence and build the validity mask.  ``seq_lens`` is a host
+    tensor; ``egpt`` / ``vl`` may live on a device, in which case the mask is built there."""
     longest = int(seq_lens.max())
-    mask = (torch.arange(longest)[None, :] < seq_lens[:, None]).float()
+    dev = egpt.device
+    lens = seq_lens.to(dev) if dev.type != "cpu" else seq_lens
+    mask = (torch.arange(longest, device=dev)[None, :] < lens[:, None]).float()
     return {"egpt_hidden": egpt[:, :longest], "vl_hidden": vl[:, :longest], "mask": mask,
             "seq_lens": seq_lens}
+
+
+def _take(t: torch.Tensor, sel: torch.Tensor) -> torch.Tensor:
+    """Rows ``sel`` (host index tensor) of ``t`` on ``t``'s device."""
+    return t.index_select(0, sel.to(t.device)) if t.device.type != "cpu" else t[sel]
+
+
+class DeviceBatchLoader:
+    """Mini-batches cut on the accelerator from a dataset that is resident there.
+
+    The host-side alternative gathers ``batch x seq x 4096`` fp32 rows twice per step (52 MB
+    each at batch 64) and uploads them from pageable memory, which bounds L1-L4 adapter
+    training at a third of what the GPU sustains; here a step uploads ``batch`` indices."""
+
+    def __init__(self, data: dict, indices: Optional[Sequence[int]], batch_size: int, device,
+                 shuffle: bool = True, seed: int = 0, drop_last: bool = False):
+        self.device = torch.device(device)
+        idx = torch.arange(data["egpt_hidden"].shape[0]) if indices is None else torch.as_tensor(list(indices))
+        self.lens = data["seq_lens"][idx].clone()
+        self.e = data["egpt_hidden"][idx].to(self.device)
+        self.v = self.e if data["vl_hidden"] is data["egpt_hidden"] else data["vl_hidden"][idx].to(self.device)
+        self.batch_size, self.shuffle, self.seed, self.drop_last = batch_size, shuffle, seed, drop_last
+        self.epoch = 0
+
+    @staticmethod
+    def fits(data: dict, device, fraction: float = 0.5) -> bool:
+        device = torch.device(device)
+        if device.type != "cuda":
+            return False
+        need = sum(data[k].numel() * data[k].element_size() for k in ("egpt_hidden", "vl_hidden"))
+        free, _ = torch.cuda.mem_get_info(device)
+        return need < fraction * free
+
+    def __len__(self) -> int:
+        n = self.lens.shape[0]
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        n = self.lens.shape[0]
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        perm = torch.randperm(n, generator=g) if self.shuffle else torch.arange(n)
+        for s in range(0, n, self.batch_size):
+            sel = perm[s:s + self.batch_size]
+            if self.drop_last and len(sel) < self.batch_size:
+                break
+            yield make_batch(_take(self.e, sel), _take(self.v, sel), self.lens[sel])
+        self.epoch += 1
 
 
 def collate_fn(items: Sequence[dict]) -> Dict[str, torch.Tensor]:
@@ -201,8 +251,10 @@ class HiddenStateDataset(torch.utils.data.Dataset):
 class _ChunkStream:
     """Background reader: yields chunk dicts in a given order, one chunk ahead."""
 
-    def __init__(self, data_dir: str, order: Sequence[int], pin: bool):
+    def __init__(self, data_dir: str, order: Sequence[int], pin: bool, device=None):
         self.data_dir, self.order, self.pin = data_dir, list(order), pin
+        self.device = torch.device(device) if device is not None else None
+        self.side = torch.cuda.Stream(self.device) if self.device is not None and self.device.type == "cuda" else None
         self.index = read_index(data_dir)
         self.q: "queue.Queue" = queue.Queue(maxsize=1)
         self.t = threading.Thread(target=self._run, daemon=True)
@@ -216,6 +268,13 @@ class _ChunkStream:
                 if self.pin and torch.cuda.is_available():
                     for k in ("egpt_hidden", "vl_hidden"):
                         d[k] = d[k].pin_memory()
+                if self.side is not None:
+                    # whole chunk to the accelerator on a side stream, while the consumer trains on
+                    # the previous one; batches are then cut on the device
+                    with torch.cuda.stream(self.side):
+                        for k in ("egpt_hidden", "vl_hidden"):
+                            d[k] = d[k].to(self.device, non_blocking=True)
+                        d["_ready"] = self.side.record_event()
                 self.q.put(d)
         except BaseException as exc:  # surfaced in the consumer thread
             self.q.put(exc)
@@ -228,6 +287,12 @@ class _ChunkStream:
                 return
             if isinstance(item, BaseException):
                 raise item
+            ev = item.pop("_ready", None)
+            if ev is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                for k in ("egpt_hidden", "vl_hidden"):   # freed blocks wait for the consumer's kernels
+                    item[k].record_stream(cur)
             yield item
 
 
@@ -242,10 +307,11 @@ class ChunkedTrainLoader:
     """
 
     def __init__(self, data_dir: str, batch_size: int = 64, shuffle: bool = True, seed: int = 0,
-                 rank: int = 0, world: int = 1, pin: bool = True, drop_last: bool = False):
+                 rank: int = 0, world: int = 1, pin: bool = True, drop_last: bool = False, device=None):
         self.data_dir, self.batch_size, self.shuffle = data_dir, batch_size, shuffle
         self.seed, self.rank, self.world, self.pin = seed, rank, world, pin
         self.drop_last = drop_last
+        self.device = device      # chunks are uploaded whole and batches cut on this device
         self.index = read_index(data_dir)
         self.epoch = 0
 
@@ -267,7 +333,7 @@ class ChunkedTrainLoader:
         g = torch.Generator().manual_seed(self.seed + self.epoch)
         n_chunks = len(self.index["chunks"])
         order = torch.randperm(n_chunks, generator=g).tolist() if self.shuffle else list(range(n_chunks))
-        for chunk in _ChunkStream(self.data_dir, order, self.pin):
+        for chunk in _ChunkStream(self.data_dir, order, self.pin, self.device):
             n = chunk["egpt_hidden"].shape[0]
             perm = torch.randperm(n, generator=g) if self.shuffle else torch.arange(n)
             if self.world > 1:
@@ -277,7 +343,7 @@ class ChunkedTrainLoader:
                 sel = perm[s:s + self.batch_size]
                 if full_only and len(sel) < self.batch_size:
                     break
-                yield make_batch(chunk["egpt_hidden"][sel], chunk["vl_hidden"][sel],
+                yield make_batch(_take(chunk["egpt_hidden"], sel), _take(chunk["vl_hidden"], sel),
                                  chunk["seq_lens"][sel])
         self.epoch += 1
 
@@ -288,8 +354,8 @@ class ChunkedValLoader(ChunkedTrainLoader):
     pipeline/adapter_train/train_hidden_adapter.py:227-242)."""
 
     def __init__(self, data_dir: str, batch_size: int = 64, rank: int = 0, world: int = 1,
-                 pin: bool = True):
-        super().__init__(data_dir, batch_size, shuffle=False, rank=rank, world=world, pin=pin)
+                 pin: bool = True, device=None):
+        super().__init__(data_dir, batch_size, shuffle=False, rank=rank, world=world, pin=pin, device=device)
 
     def __len__(self) -> int:
         return sum((self._shard(c["n_samples"]) + self.batch_size - 1) // self.batch_size
@@ -300,9 +366,9 @@ class ChunkedValLoader(ChunkedTrainLoader):
 
     def __iter__(self):
         order = list(range(len(self.index["chunks"])))
-        for chunk in _ChunkStream(self.data_dir, order, self.pin):
+        for chunk in _ChunkStream(self.data_dir, order, self.pin, self.device):
             idx = torch.arange(chunk["egpt_hidden"].shape[0])[self.rank::self.world]
             for s in range(0, len(idx), self.batch_size):
                 sel = idx[s:s + self.batch_size]
-                yield make_batch(chunk["egpt_hidden"][sel], chunk["vl_hidden"][sel],
+                yield make_batch(_take(chunk["egpt_hidden"], sel), _take(chunk["vl_hidden"], sel),
                                  chunk["seq_lens"][sel])

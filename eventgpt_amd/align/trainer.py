@@ -257,10 +257,11 @@ def build_parser() -> argparse.ArgumentParser:
 def _loaders(args, info: DistInfo):
     if os.path.isdir(args.train_data) and (args.val_data is None or os.path.isdir(args.val_data)) \
             and args.val_data is not None:
+        dev = info.device if info.device.type == "cuda" else None
         return (store.ChunkedTrainLoader(args.train_data, args.batch_size, seed=args.seed,
-                                         rank=info.rank, world=info.world),
+                                         rank=info.rank, world=info.world, device=dev),
                 store.ChunkedValLoader(args.val_data, args.batch_size, rank=info.rank,
-                                       world=info.world))
+                                       world=info.world, device=dev))
     data = store.load_hidden_states(args.train_data)
     n = data["egpt_hidden"].shape[0]
     g = torch.Generator().manual_seed(args.seed)
@@ -272,6 +273,15 @@ def _loaders(args, info: DistInfo):
         train_idx, val = perm[k:], store.HiddenStateDataset(data, perm[:k])
     train_idx = train_idx[info.rank::info.world]
     usable = (len(train_idx) // args.batch_size) * args.batch_size if info.world > 1 else len(train_idx)
+    if store.DeviceBatchLoader.fits(data, info.device):
+        # the whole set lives on the accelerator; a step uploads only its sample indices
+        if args.val_data:
+            vdata, vidx = {"egpt_hidden": val.e, "vl_hidden": val.v, "seq_lens": val.lens}, None
+        else:
+            vdata, vidx = data, val.indices
+        return (store.DeviceBatchLoader(data, train_idx[:max(usable, 1)], args.batch_size, info.device,
+                                        shuffle=True, seed=args.seed, drop_last=info.world > 1),
+                store.DeviceBatchLoader(vdata, vidx, args.batch_size, info.device, shuffle=False))
     train = store.HiddenStateDataset(data, train_idx[:max(usable, 1)])
     dl = torch.utils.data.DataLoader
     return (dl(train, batch_size=args.batch_size, shuffle=True, collate_fn=store.collate_fn,

@@ -64,3 +64,37 @@ def test_sharded_adamw_on_gpu_matches_torch(dtype):
     flat_ref = torch.cat([r.detach().reshape(-1) for r in reversed(ref)])
     flat_master = torch.cat([b.master[:b.numel] for b in opt.buckets]).cpu()
     assert torch.allclose(flat_master, flat_ref, rtol=1e-4, atol=1e-6)
+
+
+def test_device_resident_loaders_yield_the_host_loaders_batches(tmp_path):
+    """Batches cut on the GPU (whole set resident, or chunk by chunk) equal the host loaders'."""
+    from eventgpt_amd.align import store
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0)
+    w = store.ChunkedHiddenStateWriter(str(tmp_path / "s"), chunk_size=5)
+    for i in range(13):
+        n = 6 + i % 4
+        e = torch.randn(n, 32, generator=g)
+        w.add_sample(e, e * 2, {"sample_idx": i, "question_idx": 0})
+    w.flush()
+    d = str(tmp_path / "s")
+    for cls, kw in ((store.ChunkedTrainLoader, dict(seed=3)), (store.ChunkedValLoader, {})):
+        host = list(cls(d, batch_size=4, pin=False, **kw))
+        gpu = list(cls(d, batch_size=4, pin=True, device=dev, **kw))
+        assert len(host) == len(gpu) > 0
+        for a, b in zip(host, gpu):
+            assert b["egpt_hidden"].is_cuda and b["mask"].is_cuda
+            for k in ("egpt_hidden", "vl_hidden", "mask"):
+                assert torch.equal(a[k], b[k].cpu())
+            assert torch.equal(a["seq_lens"], b["seq_lens"])
+    data = store.load_hidden_states(d)
+    assert store.DeviceBatchLoader.fits(data, dev) and not store.DeviceBatchLoader.fits(data, "cpu")
+    ld = store.DeviceBatchLoader(data, [0, 2, 5, 7, 11], 2, dev, shuffle=False)
+    got = list(ld)
+    assert len(ld) == len(got) == 3 and got[-1]["egpt_hidden"].shape[0] == 1
+    want = store.make_batch(data["egpt_hidden"][[0, 2]], data["vl_hidden"][[0, 2]], data["seq_lens"][[0, 2]])
+    assert torch.equal(got[0]["egpt_hidden"].cpu(), want["egpt_hidden"]) and torch.equal(got[0]["mask"].cpu(), want["mask"])
+    # two epochs of a shuffled loader visit every sample once each, in different orders
+    sh = store.DeviceBatchLoader(data, None, 4, dev, shuffle=True, seed=1)
+    e1 = torch.cat([b["seq_lens"] for b in sh]); e2 = torch.cat([b["seq_lens"] for b in sh])
+    assert sorted(e1.tolist()) == sorted(e2.tolist()) == sorted(data["seq_lens"].tolist())
