@@ -111,8 +111,10 @@ class HiddenStateExtractor:
             return None
         m = self.egpt
         img = np.asarray(load_image(paths[0]))
-        proc = m.get_visual_tower().event_processor
-        px = proc(img, return_tensors="pt")["pixel_values"][0].to(m.device, m.dtype)
+        # resize / crop / normalise on the model's device (one kernel on a GPU, same pixels as the
+        # host processor)
+        from ..ops.event_ops import preprocess_frames
+        px = preprocess_frames([img], m.device, m.get_visual_tower().event_processor.size, m.dtype)[0]
         feats = m.get_model().feature_adaptor(m.visval_encode(px[None]))[0]
         feats = get_spatio_temporal_features([feats])[None]
         ids = tokenizer_event_token(prepare_event_prompt(query, "eventgpt_v1"), self.egpt_tok,
@@ -138,7 +140,7 @@ class HiddenStateExtractor:
         frames = load_video_frames(src, self.vl.config.num_frames)
         if not frames:
             return None
-        inputs = self.vl_proc(VIDEO_PROMPT.format(query=query), frames)
+        inputs = self.vl_proc(VIDEO_PROMPT.format(query=query), frames, device=self.vl.device, dtype=self.vl.dtype)
         emb = self.vl.prepare_embeds(inputs["input_ids"].to(self.vl.device),
                                      inputs["pixel_values_videos"].to(self.vl.device, self.vl.dtype))
         hidden, toks = _decode_with_hidden(self.vl, emb, self.max_new_tokens,
@@ -288,11 +290,14 @@ def main(argv=None) -> Dict[str, int]:
     ex = HiddenStateExtractor(egpt, tok, vl, vproc, args.max_new_tokens, args.event_image_key,
                               double_adaptor=not args.single_adaptor)
     stop = StopFlag().install()
+    t_run = time.time()
     try:
         stats = run_extraction(ex, ds, questions, writer, rank, world, stop)
     finally:
         stop.restore()
-    print(f"[extract r{rank}] done: {stats}, store {store} holds {writer.total_samples} samples", flush=True)
+    dt = time.time() - t_run
+    print(f"[extract r{rank}] done: {stats}, store {store} holds {writer.total_samples} samples; "
+          f"{dt:.1f} s, {dt / max(stats['new'] + stats['errors'], 1):.3f} s/pair", flush=True)
     if world > 1:
         import torch.distributed as dist
 
