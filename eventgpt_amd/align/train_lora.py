@@ -53,7 +53,8 @@ class LoRATrainer:
                  lora_rank: int = 16, lora_alpha: int = 32, lora_dropout: float = 0.05,
                  token_loss_weight: float = 0.1, learning_rate: float = 1e-4, gradient_accumulation: int = 16,
                  num_epochs: int = 20, early_stopping: int = 5, output_dir: str = "tasks/L6",
-                 info: Optional[DistInfo] = None, double_adaptor: bool = True, max_samples: int = -1):
+                 info: Optional[DistInfo] = None, double_adaptor: bool = True, max_samples: int = -1,
+                 gradient_checkpointing: str = "auto"):
         self.model, self.tok = model, tokenizer
         self.train_chunks, self.val_chunks = train_chunks, val_chunks
         self.ds = InstructionDataset(dataset_dir)
@@ -66,7 +67,13 @@ class LoRATrainer:
         self.double_adaptor, self.max_samples = double_adaptor, max_samples
         self.device = model.device
         self.wrapped = apply_lora(model, lora_rank, lora_alpha, lora_dropout)
-        model.model.gradient_checkpointing = True
+        # The reference recomputes every block in backward to fit a 24 GB card
+        # (train_lora_adapter.py:335-402); the activations of one ~700-token sample are a few
+        # GB, so with tens of GB free the recomputation (one extra forward per step) is skipped.
+        if gradient_checkpointing == "auto":
+            roomy = self.device.type == "cuda" and torch.cuda.mem_get_info(self.device)[0] > (48 << 30)
+            gradient_checkpointing = "off" if roomy else "on"
+        model.model.gradient_checkpointing = gradient_checkpointing == "on"
         self.vl_lm_head = vl_lm_head.to(self.device, torch.float32) if vl_lm_head is not None else None
         if self.info.world > 1:
             # LoRA A matrices are randomly initialised: every rank starts from rank 0's
@@ -266,6 +273,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--random_init", default=None, choices=["7b", "tiny"])
     p.add_argument("--single_adaptor", action="store_true")
     p.add_argument("--max_samples", type=int, default=-1, help="cap on samples per chunk and rank (smoke runs)")
+    p.add_argument("--gradient_checkpointing", default="auto", choices=["auto", "on", "off"],
+                   help="auto: recompute blocks in backward only when the device has < 48 GB free")
     p.add_argument("--cpu", action="store_true")
     return p
 
@@ -291,7 +300,7 @@ def main(argv=None) -> Dict:
                           args.val_dataset_dir, args.event_image_key, args.lora_rank, args.lora_alpha,
                           args.lora_dropout, args.token_loss_weight, args.learning_rate,
                           args.gradient_accumulation, args.num_epochs, args.early_stopping, out, info,
-                          not args.single_adaptor, args.max_samples)
+                          not args.single_adaptor, args.max_samples, args.gradient_checkpointing)
     if info.is_main:
         print(f"[L6] {trainer.params['trainable']:,} trainable of {trainer.params['total']:,} parameters "
               f"({trainer.params['percent']:.3f}%), {len(trainer.wrapped)} wrapped layers, world {info.world}",
