@@ -65,11 +65,12 @@ class SampleInputs:
         if not frames:
             return None
         img = np.asarray(load_image(paths[0]))
-        proc = self.egpt.get_visual_tower().event_processor
-        ev_px = proc(img, return_tensors="pt")["pixel_values"][0]
+        from ..ops.event_ops import preprocess_frames
+        ev_px = preprocess_frames([img], self.egpt.device, self.egpt.get_visual_tower().event_processor.size,
+                                  self.egpt.dtype)[0]
         ev_ids = tokenizer_event_token(prepare_event_prompt(query, "eventgpt_v1"), self.egpt_tok,
                                        EVENT_TOKEN_INDEX, return_tensors="pt")[None]
-        vin = self.vl_proc(VIDEO_PROMPT.format(query=query), frames)
+        vin = self.vl_proc(VIDEO_PROMPT.format(query=query), frames, device=self.vl.device, dtype=self.vl.dtype)
         return {"ev_px": ev_px, "ev_ids": ev_ids, "ev_size": list(img.shape[:2]),
                 "vl_ids": vin["input_ids"], "vl_px": vin["pixel_values_videos"]}
 
