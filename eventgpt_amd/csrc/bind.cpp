@@ -361,19 +361,21 @@ void decode_qkv(const Tensor& x, const Tensor& norm_w, const Tensor& w_qkv, cons
                               (int)D, (int)k_cache.size(2), (int)K, cur_stream(), one_seq ? 1 : 0);
 }
 
-// dx (and, when dw is given, dw += the weight gradient in fp32) of y = rmsnorm(x) * w
-Tensor rmsnorm_bwd(const Tensor& x, const Tensor& w, const Tensor& g, double eps,
-                   const c10::optional<Tensor>& dw) {
+// (dx, dw): dw is the fp32 weight gradient when want_dw, else an empty tensor
+std::tuple<Tensor, Tensor> rmsnorm_bwd(const Tensor& x, const Tensor& w, const Tensor& g, double eps,
+                                       bool want_dw) {
   check_bf16(x, "x"); check_bf16(w, "weight"); check_bf16(g, "grad");
   const int64_t H = x.size(-1), rows = x.numel() / H;
   TORCH_CHECK(H % 8 == 0 && H <= 8192 && w.numel() == H && g.numel() == x.numel(),
               "rmsnorm_bwd: hidden size must be a multiple of 8 up to 8192");
   Tensor dx = at::empty_like(x);
-  float* dwp = nullptr;
-  if (dw.has_value()) { check_f32(*dw, "dw"); TORCH_CHECK(dw->numel() == H); dwp = dw->data_ptr<float>(); }
-  evgpt::launch_rmsnorm_bwd(bptr(x), bptr(w), bptr(g), bptr_mut(dx), dwp, (int)rows, (int)H, (float)eps,
-                            cur_stream());
-  return dx;
+  Tensor part;
+  if (want_dw && rows > 0)
+    part = at::empty({(int64_t)evgpt::rmsnorm_bwd_blocks((int)rows, true), H}, x.options().dtype(at::kFloat));
+  evgpt::launch_rmsnorm_bwd(bptr(x), bptr(w), bptr(g), bptr_mut(dx), part.defined() ? part.data_ptr<float>() : nullptr,
+                            (int)rows, (int)H, (float)eps, cur_stream());
+  Tensor dw = part.defined() ? part.sum(0) : at::zeros({want_dw ? H : 0}, x.options().dtype(at::kFloat));
+  return std::make_tuple(dx, dw);
 }
 
 Tensor swiglu_bwd(const Tensor& gate_up, const Tensor& gh) {
@@ -785,7 +787,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("decode_qkv(Tensor x, Tensor norm_w, Tensor w_qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos, float eps, int Hq, int Hkv, int D, bool one_seq=False) -> ()", &decode_qkv);
   m.def("decode_attn(Tensor q, Tensor k_cache, Tensor v_cache, Tensor(a!) out, Tensor(b!) part_o, Tensor(c!) part_ml, Tensor pos, int nsplit, float scale) -> ()", &decode_attn);
   m.def("decode_gemv_residual(Tensor w, Tensor xin, Tensor(a!) y) -> ()", &decode_gemv_residual);
-  m.def("rmsnorm_bwd(Tensor x, Tensor weight, Tensor grad, float eps, Tensor(a!)? dw=None) -> Tensor", &rmsnorm_bwd);
+  m.def("rmsnorm_bwd(Tensor x, Tensor weight, Tensor grad, float eps, bool want_dw=False) -> (Tensor, Tensor)", &rmsnorm_bwd);
   m.def("swiglu_bwd(Tensor gate_up, Tensor grad) -> Tensor", &swiglu_bwd);
   m.def("fused_adamw(Tensor grad, Tensor(a!) master, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor(d!) param_out, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float clip) -> ()", &fused_adamw);
   m.def("w4_dequant(Tensor packed, Tensor absmax, Tensor code, Tensor(a!)? out=None) -> Tensor", &w4_dequant);

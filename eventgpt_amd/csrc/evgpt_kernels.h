@@ -34,6 +34,7 @@ void launch_gemv_logits(const bf16_t* W, const bf16_t* x, const bf16_t* norm_w, 
                         hipStream_t st);
 
 // ---- train_bwd.hip
+int rmsnorm_bwd_blocks(int rows, bool with_dw);   // rows of the [blocks][H] fp32 dw partial buffer
 void launch_rmsnorm_bwd(const bf16_t* x, const bf16_t* w, const bf16_t* g, bf16_t* dx, float* dw, int rows,
                         int H, float eps, hipStream_t st);
 void launch_swiglu_bwd(const bf16_t* gate_up, const bf16_t* gh, bf16_t* dgu, long long M, int I, hipStream_t st);

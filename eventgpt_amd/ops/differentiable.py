@@ -54,9 +54,9 @@ class _RMSNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        dw = torch.zeros(w.numel(), dtype=torch.float32, device=w.device) if ctx.needs_input_grad[1] else None
-        dx = _raw().rmsnorm_bwd(x, w.contiguous(), g.contiguous(), ctx.eps, dw)
-        return dx, (None if dw is None else dw.to(w.dtype).view_as(w)), None
+        want_dw = bool(ctx.needs_input_grad[1])
+        dx, dw = _raw().rmsnorm_bwd(x, w.contiguous(), g.contiguous(), ctx.eps, want_dw)
+        return dx, (dw.to(w.dtype).view_as(w) if want_dw else None), None
 
 
 class _Rope(torch.autograd.Function):
