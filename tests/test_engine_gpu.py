@@ -236,3 +236,25 @@ def test_grouped_query_attention_engine_matches_module(dev, heads, kv_heads, hid
         assert res[0] >= G - 1, (G, res, t_graph[:G + 2].tolist())
         if res[0] == G:
             assert res[1] == int(t_graph[1 + G]), (G, res, t_graph[:G + 2].tolist())
+
+
+@pytest.mark.parametrize("B", [2, 6])
+def test_batched_engine_with_grouped_kv_heads(dev, B):
+    """The batched decode paths (GEMV rows and split-K GEMM rows) with fewer K/V than query heads."""
+    from eventgpt_amd.parallel.tp import TensorParallelEngine
+    cfg = EventChatConfig(vocab_size=777, hidden_size=512, intermediate_size=1408, num_hidden_layers=2,
+                          num_attention_heads=8, num_key_value_heads=2, max_position_embeddings=512,
+                          torch_dtype="bfloat16")
+    m = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=9)
+    prompts = [(torch.randn(18 + 4 * b, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(40 + b))
+                * 0.5).to(torch.bfloat16) for b in range(B)]
+    single = m.engine(max_len=256, max_new_tokens=32)
+    want = [single.generate(p, 10, eos_token_id=-1) for p in prompts]
+    eng = TensorParallelEngine(m, None, max_len=256, max_batch=B, max_new_tokens=32)
+    eng.eos = -1
+    eng.prefill_batch(prompts)
+    for _ in range(9):
+        eng.decode_step(True)
+    for b in range(B):
+        got = eng.tokens(b)
+        assert (got == want[b]).long().cumprod(0).sum().item() >= 5, (b, got.tolist(), want[b].tolist())
