@@ -258,3 +258,31 @@ def test_batched_engine_with_grouped_kv_heads(dev, B):
     for b in range(B):
         got = eng.tokens(b)
         assert (got == want[b]).long().cumprod(0).sum().item() >= 5, (b, got.tolist(), want[b].tolist())
+
+
+def test_long_prompt_prefill_and_decode(dev):
+    """A 2 500-token prompt (past the 2 048 the reference truncates to): prefill hidden states and
+    cache against the module path, then decode against a cache that long (graph == eager)."""
+    cfg = EventChatConfig(vocab_size=600, hidden_size=256, intermediate_size=704, num_hidden_layers=2,
+                          num_attention_heads=4, max_position_embeddings=4096, torch_dtype="bfloat16")
+    m = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=11)
+    S = 2500
+    emb = (torch.randn(S, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(2)) * 0.5).to(torch.bfloat16)
+    eng = m.engine(max_len=3072, max_new_tokens=32)
+    eng.reset()
+    h = eng.prefill(emb, select=None, return_hidden=True)
+    ref = m.model(inputs_embeds=emb[None], use_cache=True)
+    from eventgpt_amd import ops
+    hn = ops.rmsnorm(h, m.model.norm.weight, cfg.rms_norm_eps).float()
+    want = ref.last_hidden_state[0].float()
+    cos = torch.nn.functional.cosine_similarity(hn, want, dim=-1)
+    assert cos.min().item() > 0.995 and (hn - want).abs().max().item() < 0.25
+    k_mod = ref.past_key_values[1][0][0]
+    assert (k_mod.float() - eng.layers[1].k_cache[0, :, :S].float()).abs().max().item() < 0.1
+    eng.use_graph = False
+    t_eager = eng.generate(emb, 12, eos_token_id=-1)
+    eng.use_graph = True
+    assert torch.equal(eng.generate(emb, 12, eos_token_id=-1), t_eager)
+    assert int(eng.pos[0]) == S + 11          # the prefill commits token 1, eleven decode steps follow
+    with pytest.raises(ValueError):
+        eng.prefill(torch.zeros(3073, 256, dtype=torch.bfloat16, device=dev), start=0)
