@@ -66,8 +66,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_split_kernel(
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) s += qf[2 * i] * bf16lo(kv[u][i]) + qf[2 * i + 1] * bf16hi(kv[u][i]);
-#pragma unroll
-      for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      s = group_sum<LPK>(s);   // the LPK lanes of one key row
       if (key[u] >= 0) {
         const float mn = fmaxf(m, s);
         const float a = __expf(m - mn), p = __expf(s - mn);

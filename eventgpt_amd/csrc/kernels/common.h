@@ -62,6 +62,18 @@ __device__ __forceinline__ float dpp_add(float v) {
   const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
   return v + __int_as_float(moved);
 }
+// Sum over aligned groups of 8 or 16 lanes (a DPP row is 16 lanes), result in every lane of
+// the group: 3 or 4 VALU adds, no LDS-pipe traffic.
+template <int LANES>
+__device__ __forceinline__ float group_sum(float v) {
+  static_assert(LANES == 8 || LANES == 16, "group of 8 or 16 lanes");
+  v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);   // row_half_mirror: 8-lane sums
+  if constexpr (LANES == 16) v = dpp_add<0x140, 0xF>(v);   // row_mirror: 16-lane sums
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
   v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
   v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
