@@ -36,12 +36,8 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_split_kernel(
   const int g0 = split * gper;
   const int g1 = min(g0 + gper, ngroups);
 
-  float qf[8];
-  {
-    u32x4_t qv = load16(q + (static_cast<size_t>(b) * Hq + h) * D + dl * 8);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { qf[2 * i] = bf16lo(qv[i]) * scale; qf[2 * i + 1] = bf16hi(qv[i]) * scale; }
-  }
+  // q stays packed: the score is four v_dot2 per lane and one multiply by the scale
+  const u32x4_t qv = load16(q + (static_cast<size_t>(b) * Hq + h) * D + dl * 8);
   const bf16_t* kb = k_cache + (static_cast<size_t>(b) * Hkv + hk) * l_max * D + dl * 8;
   const bf16_t* vb = v_cache + (static_cast<size_t>(b) * Hkv + hk) * l_max * D + dl * 8;
 
@@ -61,24 +57,30 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_split_kernel(
       vv[u] = load16(vb + static_cast<size_t>(kk) * D);
       if (!ok) key[u] = -1;
     }
+    // scores of the U keys first, then ONE rescale of the running state by the new maximum
+    // (per key it is eight multiplies more), then the U weighted value rows
+    float sc[U];
+    float mn = m;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      float s = 0.f;
+      sc[u] = group_sum<LPK>(dot8_bf16(qv, kv[u], 0.f)) * scale;   // the LPK lanes of one key row
+      if (key[u] >= 0) mn = fmaxf(mn, sc[u]);
+    }
+    const float a = (mn == -INFINITY) ? 1.f : __expf(m - mn);   // m == -inf: state is all zeros
+    l *= a;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s += qf[2 * i] * bf16lo(kv[u][i]) + qf[2 * i + 1] * bf16hi(kv[u][i]);
-      s = group_sum<LPK>(s);   // the LPK lanes of one key row
-      if (key[u] >= 0) {
-        const float mn = fmaxf(m, s);
-        const float a = __expf(m - mn), p = __expf(s - mn);
-        l = l * a + p;
+    for (int i = 0; i < 8; ++i) o[i] *= a;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          o[2 * i] = o[2 * i] * a + p * bf16lo(vv[u][i]);
-          o[2 * i + 1] = o[2 * i + 1] * a + p * bf16hi(vv[u][i]);
-        }
-        m = mn;
+    for (int u = 0; u < U; ++u) {
+      const float p = key[u] >= 0 ? __expf(sc[u] - mn) : 0.f;
+      l += p;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[2 * i] += p * bf16lo(vv[u][i]);
+        o[2 * i + 1] += p * bf16hi(vv[u][i]);
       }
     }
+    m = mn;
   }
 
   // merge the KPW lane groups of this wave (lanes with equal dl)
