@@ -5,7 +5,8 @@ import time
 
 import torch
 
-from eventgpt_amd.models import EventChatConfig, EventChatModel
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from eventgpt_amd.models import EventChatConfig, EventChatModel  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 2115
