@@ -31,9 +31,11 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   __bf16 b = static_cast<__bf16>(f);
   return __builtin_bit_cast(bf16_t, b);
 }
+// One v_cvt_pk_bf16_f32 for the pair (two scalar casts + shift + or are four instructions).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-  return static_cast<unsigned int>(f32_to_bf16(lo)) |
-         (static_cast<unsigned int>(f32_to_bf16(hi)) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float bf16lo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
