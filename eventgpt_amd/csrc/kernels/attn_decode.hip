@@ -83,33 +83,26 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_split_kernel(
     m = mn;
   }
 
-  // merge the KPW lane groups of this wave (lanes with equal dl)
-#pragma unroll
-  for (int off = LPK; off < 64; off <<= 1) {
-    const float om = __shfl_xor(m, off, 64), ol = __shfl_xor(l, off, 64);
-    const float mn = fmaxf(m, om);
-    const float a = (m == -INFINITY) ? 0.f : __expf(m - mn);
-    const float c = (om == -INFINITY) ? 0.f : __expf(om - mn);
-    l = l * a + ol * c;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = o[i] * a + __shfl_xor(o[i], off, 64) * c;
-    m = mn;
-  }
-
-  // merge the waves through LDS
-  __shared__ float s_o[AD_WAVES][D];
-  __shared__ float s_m[AD_WAVES], s_l[AD_WAVES];
-  if (sub == 0) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s_o[wid][dl * 8 + i] = o[i];
-    if (dl == 0) { s_m[wid] = m; s_l[wid] = l; }
+  // Every 16-lane (8-lane for D = 64) group of every wave holds a partial (m, l, o): all of them
+  // go to LDS and are merged in one pass.  Merging the groups of a wave with cross-lane
+  // exchanges first costs 20 ds_bpermute per wave on the CU's shared LDS pipe.
+  constexpr int NP = AD_WAVES * KPW;
+  __shared__ __attribute__((aligned(16))) float s_o[NP][D];
+  __shared__ float s_m[NP], s_l[NP];
+  {
+    const int pidx = wid * KPW + sub;
+    *reinterpret_cast<f32x4_t*>(&s_o[pidx][dl * 8]) = f32x4_t{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4_t*>(&s_o[pidx][dl * 8 + 4]) = f32x4_t{o[4], o[5], o[6], o[7]};
+    if (dl == 0) { s_m[pidx] = m; s_l[pidx] = l; }
   }
   __syncthreads();
   if (tid < D) {
     float mm = s_m[0];
-    for (int w = 1; w < AD_WAVES; ++w) mm = fmaxf(mm, s_m[w]);
+#pragma unroll
+    for (int w = 1; w < NP; ++w) mm = fmaxf(mm, s_m[w]);
     float ll = 0.f, oo = 0.f;
-    for (int w = 0; w < AD_WAVES; ++w) {
+#pragma unroll
+    for (int w = 0; w < NP; ++w) {
       const float c = (s_m[w] == -INFINITY) ? 0.f : __expf(s_m[w] - mm);
       ll += s_l[w] * c;
       oo += s_o[w][tid] * c;
