@@ -112,7 +112,8 @@ def preprocess_frames(frames, device, size: int = CLIP_IMAGE_SIZE, dtype=torch.b
             return clip_preprocess_gpu(u8, size).to(dtype)
         # rasters of one clip can differ in size (the canvas follows each slice's extent):
         # one kernel call per frame, still two orders of magnitude faster than the host path
-        outs = [clip_preprocess_gpu(torch.from_numpy(np.ascontiguousarray(a))[None].to(device), size)
+        # (np.array copies: image decoders hand out read-only buffers, which from_numpy warns about)
+        outs = [clip_preprocess_gpu(torch.from_numpy(np.array(a, order="C"))[None].to(device), size)
                 for a in arrs]
         return torch.cat(outs).to(dtype)
     px = [torch.from_numpy(cp.preprocess_image(a, size)) for a in arrs]
