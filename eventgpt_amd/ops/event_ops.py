@@ -59,6 +59,26 @@ def voxel_grid_gpu(ev: Dict[str, torch.Tensor], bins: int = 5,
                                size[1], signed, by == "count")
 
 
+_AXIS_CACHE: Dict[tuple, tuple] = {}
+
+
+def _axis_table(n_in: int, n_out: int, device) -> tuple:
+    """Device copies of the resample table of one axis (start, count, weight), cached per
+    ``(n_in, n_out)``: clips whose rasters differ in one extent still share the other axis."""
+    key = (n_in, n_out, str(device))
+    hit = _AXIS_CACHE.get(key)
+    if hit is None:
+        def dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+        if n_out != n_in:
+            t = cp.resample_table(n_in, n_out)
+            hit = (dev(t.start), dev(t.count), dev(t.weight))
+        else:
+            hit = (dev(np.zeros(1)), dev(np.zeros(1)), dev(np.zeros((1, 1))))
+        _AXIS_CACHE[key] = hit
+    return hit
+
+
 def _tables(h: int, w: int, size: int, device) -> tuple:
     key = (h, w, size, str(device))
     hit = _TABLE_CACHE.get(key)
@@ -66,23 +86,8 @@ def _tables(h: int, w: int, size: int, device) -> tuple:
         return hit
     rh, rw = cp.resized_shape(h, w, size)
     top, left = cp.center_crop_offsets(rh, rw, size)
-
-    def dev(a):
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
-
-    dummy = dev(np.zeros(1))
-    if rw != w:
-        th = cp.resample_table(w, rw)
-        hs, hc, hw = dev(th.start), dev(th.count), dev(th.weight)
-    else:
-        hs = hc = dummy
-        hw = dev(np.zeros((1, 1)))
-    if rh != h:
-        tv = cp.resample_table(h, rh)
-        vs, vc, vw = dev(tv.start), dev(tv.count), dev(tv.weight)
-    else:
-        vs = vc = dummy
-        vw = dev(np.zeros((1, 1)))
+    hs, hc, hw = _axis_table(w, rw, device)
+    vs, vc, vw = _axis_table(h, rh, device)
     out = (hs, hc, hw, vs, vc, vw, rh, rw, top, left)
     _TABLE_CACHE[key] = out
     return out
