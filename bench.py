@@ -1,33 +1,43 @@
 #!/usr/bin/env python
-"""Headline benchmark: EventGPT-7B bf16 greedy decode tokens/s (+ event-prefill ms).
+"""Headline benchmark: EventGPT-7B bf16 greedy decode tokens/s (+ event-prefill ms) at 1..8 GPUs.
 
 Matches the reference's headline measurement (decode throughput 54.0 tok/s,
-LLM prefill 66.2 ms @ 636 tokens, vision 5.9 ms/frame on an RTX 4090 —
+LLM prefill 66.2 ms @ 636 tokens, vision 5.9 ms/frame on an RTX 4090 --
 feasible/benchmark_inference/BENCHMARK_1FRAME_VS_8FRAMES_20260124_193405.md:18-29):
-EventGPT-7B (Vicuna-7B decoder + CLIP ViT-L/14-336 tower), bf16, batch 1 per
-stream, greedy, 1 event frame -> 636-token multimodal prompt.
+EventGPT-7B (Vicuna-7B decoder + CLIP ViT-L/14-336 tower), bf16, batch 1,
+greedy, 1 event frame -> 636-token multimodal prompt.
 
     python bench.py --gpus N --steps K --warmup W
 
-A *step* is one decode step (one new token per stream).  With N > 1 (launched
-under ``python -m torch.distributed.run``) every rank serves its own stream
-(data-parallel replicas, weak scaling) and the reported value is the total
-tokens/s over all ranks; ``--parallelism tp`` instead shards the decoder
-tensor-parallel over the N GPUs for one stream (strong scaling).
+A *step* is one decode step (one new token per stream).
 
-Weights are random-initialised with the 7B architecture and the prompt is a
-synthetic event stream (no checkpoints or datasets are reachable here).
-Rank 0 prints exactly one JSON line.
+* N = 1: the single-GPU serving engine (``runtime/engine.py``).
+* N > 1: one process per GPU over RCCL.  Started without a torchrun environment, this
+  script launches the N ranks itself (``python -m torch.distributed.run``, before anything
+  in this process touches a GPU) and relays rank 0's JSON line.  The default parallelism is
+  tensor-parallel (``parallel/tp.py``): the SAME single stream is served by N GPUs -- strong
+  scaling, every decode step crosses 64 all-reduces -- and ``value`` is its tokens/s.  The
+  batched configuration (32 event streams on the same TP group) is measured in the same run
+  and reported under ``tp_batch32``.  ``--parallelism dp`` (independent replicas, no
+  communication in the step) is available but is never the default: its curve says nothing
+  about the fabric.
+
+The JSON line carries ``rccl_world_size`` (the result of an actual all-reduce of ones),
+``graph_captured`` (False if the decode step fell back to eager launches) and
+``tp_allreduce`` (``rccl`` or ``oneshot``), so a fallback cannot pass for the real thing.
+
+Weights are random-initialised with the 7B architecture and the prompt is a synthetic event
+stream (no checkpoints or datasets are reachable here).  Rank 0 prints exactly one JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
@@ -36,7 +46,7 @@ BASELINE_PREFILL_MS = 66.16
 BASELINE_VISION_MS = 5.93
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
@@ -45,64 +55,165 @@ def main():
                     help="multimodal prompt length (636 = 1 event frame: 578 event + 58 text)")
     ap.add_argument("--frames", type=int, default=1)
     ap.add_argument("--max-len", type=int, default=2048, help="KV-cache capacity per stream")
-    ap.add_argument("--parallelism", choices=["dp", "tp"], default="dp")
+    ap.add_argument("--parallelism", choices=["tp", "dp"], default="tp",
+                    help="multi-GPU mode: tp = one stream over N GPUs (strong scaling, default); "
+                         "dp = N independent replicas (weak scaling, no communication)")
     ap.add_argument("--model", choices=["7b", "small"], default="7b")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--batch", type=int, default=1,
                     help="event streams decoded together per engine (32 = the batched serving config)")
+    ap.add_argument("--no-batch32", action="store_true",
+                    help="multi-GPU tp runs: skip the additional 32-stream measurement")
     ap.add_argument("--nsplit", type=int, default=None, help="KV splits of the decode attention")
+    ap.add_argument("--allreduce", choices=["rccl", "oneshot", "auto"], default=None,
+                    help="tensor-parallel collective (default: EVGPT_TP_ALLREDUCE or rccl)")
     ap.add_argument("--weight-format", choices=["bf16", "nf4", "fp4"], default="bf16",
                     help="nf4/fp4: the reference's 4-bit rows (bitsandbytes load_in_4bit); not the headline config")
-    args = ap.parse_args()
+    ap.add_argument("--probe", action="store_true",
+                    help="launcher check: every rank joins a CPU (gloo) group, all-reduces a one and rank 0 "
+                         "prints the world size; no GPU is touched")
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(n: int, argv, port: int):
+    """The command that runs this script as ``n`` ranks of one node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Start ``n`` fresh ranks as a child job and wait for it.  The parent never initialises a
+    GPU (a process that has must not be replaced or forked into ranks)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env["EVGPT_BENCH_CHILD"] = "1"
+    return subprocess.call(launch_command(n, list(argv), _free_port()), env=env)
+
+
+def probe_main(args) -> None:
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    dist = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"probe": True, "n_gpus": world, "rccl_world_size": seen, "requested": args.gpus,
+                          "scaling": "strong" if (args.parallelism == "tp" and world > 1) else "weak"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
+
+# --------------------------------------------------------------------- bench
+def build_model(args, dev):
+    import torch
     from eventgpt_amd.models import ClipVisionConfig, EventChatConfig, EventChatModel
-    from eventgpt_amd.data import EventImageProcessor, event_frames, synthetic_events
-
     if args.model == "7b":
         cfg = EventChatConfig.eventgpt_7b(vocab_size=32003)
-        model_name = "EventGPT-7B (Vicuna-7B + CLIP ViT-L/14-336, random init)"
+        name = "EventGPT-7B (Vicuna-7B + CLIP ViT-L/14-336, random init)"
     else:
         cfg = EventChatConfig(vocab_size=32003, hidden_size=1024, intermediate_size=2816,
                               num_hidden_layers=4, num_attention_heads=8,
                               mm_visual_tower="small", event_feature_adaptor=True)
         cfg.vision_config = ClipVisionConfig(hidden_size=256, intermediate_size=1024,
                                              num_hidden_layers=2, num_attention_heads=4)
-        model_name = "small-debug"
-    # tensor-parallel ranks are shards of ONE model and must see identical inputs;
-    # data-parallel ranks are independent replicas with their own streams
-    data_seed = 0 if (args.parallelism == "tp" and world > 1) else rank
-    torch.manual_seed(1234 + data_seed)
+        name = "small-debug"
     model = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=1234)
+    return cfg, model, name
 
+
+def build_engine(args, model, dist, tp: bool, batch: int):
     ekw = {} if args.nsplit is None else {"nsplit": args.nsplit}
     if args.weight_format != "bf16":
         ekw["weight_format"] = args.weight_format
-    tp = args.parallelism == "tp" and world > 1
-    if tp or args.batch > 1:
+    budget = args.steps + args.warmup + 8
+    if tp or batch > 1:
         from eventgpt_amd.parallel.tp import TensorParallelEngine
-        ekw["max_batch"] = args.batch
-        engine = TensorParallelEngine(model, dist.group.WORLD if tp else None, max_len=args.max_len,
-                                      max_new_tokens=args.steps + args.warmup + 8,
-                                      use_graph=not args.no_graph, **ekw)
-    else:
-        engine = model.engine(max_len=args.max_len, max_new_tokens=args.steps + args.warmup + 8,
-                              use_graph=not args.no_graph, **ekw)
+        return TensorParallelEngine(model, dist.group.WORLD if tp else None, max_len=args.max_len,
+                                    max_batch=batch, max_new_tokens=budget, use_graph=not args.no_graph,
+                                    allreduce=args.allreduce, **ekw)
+    return model.engine(max_len=args.max_len, max_new_tokens=budget, use_graph=not args.no_graph, **ekw)
+
+
+def timed_decode(args, engine, embeds, batch: int, dist, dev):
+    """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; MAX over ranks."""
+    import torch
 
     def sync_all():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    engine.eos = -1
+    engine.reset()
+    if batch == 1:
+        engine.prefill(embeds)
+    else:
+        engine.prefill_batch([embeds] * batch)
+    for _ in range(args.warmup):
+        engine.decode_step(True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        engine.decode_step(True)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if getattr(engine, "oneshot", None) is not None:
+        engine.oneshot.check()          # a timed-out device wait must fail the run, not colour it
+    return dt
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    in_job = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not in_job:
+        # no torchrun environment: become the launcher (nothing below has touched a GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
+    if args.probe:
+        return probe_main(args)
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    rccl_world = 1
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                      # the collective really spans `world` GPUs
+        rccl_world = int(ones.item())
+
+    from eventgpt_amd.data import EventImageProcessor, event_frames, synthetic_events
+
+    tp = args.parallelism == "tp" and world > 1
+    # tensor-parallel ranks are shards of ONE model and must see identical inputs;
+    # data-parallel ranks are independent replicas with their own streams
+    data_seed = 0 if (tp or world == 1) else rank
+    torch.manual_seed(1234 + data_seed)
+    cfg, model, model_name = build_model(args, dev)
 
     # ---- event prefill: raster -> CLIP preprocess -> ViT -> projector -> pool
     proc = EventImageProcessor(cfg.vision_config.image_size)
@@ -127,7 +238,9 @@ def main():
         embeds = torch.cat([text[:35], feats.to(text.dtype), text[35:]])  # splice position of <event>
     S = embeds.shape[0]
 
-    # ---- LLM prefill latency (one stream)
+    engine = build_engine(args, model, dist, tp, args.batch)
+
+    # ---- LLM prefill latency (one stream; sharded over the TP group when there is one)
     def prefill_once():
         engine.reset()
         engine.prefill(embeds, select="greedy" if args.batch == 1 else None)
@@ -142,27 +255,26 @@ def main():
     torch.cuda.synchronize()
     prefill_ms = (time.perf_counter() - t0) * 1e3 / n_pf
 
-    # ---- decode: W warm-up steps, then exactly K timed steps
-    engine.eos = -1
-    engine.reset()
-    if args.batch == 1:
-        engine.prefill(embeds)
-    else:
-        engine.prefill_batch([embeds] * args.batch)
-    for _ in range(args.warmup):
-        engine.decode_step(True)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        engine.decode_step(True)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # ---- decode
+    dt = timed_decode(args, engine, embeds, args.batch, dist, dev)
     streams = (1 if tp else world) * args.batch
     tok_s = streams * args.steps / dt
+    graph_captured = bool(engine.graph_captured)
+    graph_fallback = engine.graph_fallback
+    tp_allreduce = getattr(engine, "allreduce_kind", "none")
+
+    # ---- the batched TP configuration (32 event streams), same group, same run
+    extra = {}
+    if tp and args.batch == 1 and not args.no_batch32:
+        del engine, model
+        torch.cuda.empty_cache()
+        _, model32, _ = build_model(args, dev)
+        eng32 = build_engine(args, model32, dist, True, 32)
+        dt32 = timed_decode(args, eng32, embeds, 32, dist, dev)
+        extra["tp_batch32"] = {"tokens_per_s": round(32 * args.steps / dt32, 2),
+                               "ms_per_step": round(dt32 * 1e3 / args.steps, 4), "global_batch": 32,
+                               "graph_captured": bool(eng32.graph_captured),
+                               "tp_allreduce": getattr(eng32, "allreduce_kind", "none")}
     if rank == 0:
         print(json.dumps({
             "metric": "decode tokens/sec (EventGPT-7B bf16 greedy, bs 1 per stream)" if args.batch == 1
@@ -170,7 +282,7 @@ def main():
             "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "strong" if tp else "weak",
+            "scaling": "strong" if (tp or world == 1) else "weak",
             "vs_baseline": round(tok_s / BASELINE_DECODE_TOK_S, 3),
             "dtype": "bf16" if args.weight_format == "bf16" else f"bf16 compute, {args.weight_format} weights",
             "data": "synthetic event stream, random-init weights",
@@ -178,6 +290,9 @@ def main():
             "event_prefill_vs_baseline": round(BASELINE_PREFILL_MS / prefill_ms, 3),
             "vision_ms_per_frame": round(vision_ms / args.frames, 3),
             "vision_vs_baseline": round(BASELINE_VISION_MS / (vision_ms / args.frames), 3),
+            "rccl_world_size": rccl_world, "graph_captured": graph_captured,
+            "graph_fallback": graph_fallback, "tp_allreduce": tp_allreduce,
+            **extra,
             "config": {"model": model_name, "global_batch": streams, "seq_len": S,
                        "event_frames": args.frames,
                        "parallelism": f"{args.parallelism}{world}"},

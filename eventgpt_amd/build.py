@@ -87,7 +87,10 @@ def sources():
     return hip, cpp
 
 
-def build(force: bool = False, verbose: bool = False, jobs: int = 8) -> str:
+def build(force: bool = False, verbose: bool = False, jobs: int = 8, extra: str = "",
+          out: str = SO_PATH) -> str:
+    """``extra``: more hipcc flags for the kernels (``-DEVGPT_...=n`` tuning variants);
+    ``out``: where to link (a variant goes next to ``_C.so`` and is picked with ``EVGPT_SO``)."""
     hip, cpp = sources()
     inc, torch_lib = _torch_paths()
     inc_flags = [f"-I{p}" for p in inc] + [f"-I{CSRC}"]
@@ -97,15 +100,15 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 8) -> str:
                   "-Wno-unknown-warning-option", "-Wno-unused-command-line-argument"] + inc_flags
     if force and os.path.isdir(BUILD_DIR):
         shutil.rmtree(BUILD_DIR)
-    tasks = [(s, HIP_FLAGS + [f"-I{CSRC}"]) for s in hip] + [(s, host_flags) for s in cpp]
+    tasks = [(s, HIP_FLAGS + extra.split() + [f"-I{CSRC}"]) for s in hip] + [(s, host_flags) for s in cpp]
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(lambda t: _compile(t[0], t[1], verbose), tasks))
     stamp = hashlib.sha256(" ".join(sorted(objs)).encode()).hexdigest()[:16]
-    stamp_file = os.path.join(BUILD_DIR, "link.stamp")
-    if (not force and os.path.exists(SO_PATH) and os.path.exists(stamp_file)
+    stamp_file = os.path.join(BUILD_DIR, os.path.basename(out) + ".link.stamp")
+    if (not force and os.path.exists(out) and os.path.exists(stamp_file)
             and open(stamp_file).read() == stamp):
-        return SO_PATH
-    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", SO_PATH,
+        return out
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", out,
            f"-L{torch_lib}", "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip", "-lc10_hip",
            f"-Wl,-rpath,{torch_lib}"]
     if verbose:
@@ -116,7 +119,7 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 8) -> str:
         raise RuntimeError("link failed")
     with open(stamp_file, "w") as f:
         f.write(stamp)
-    return SO_PATH
+    return out
 
 
 def main():
@@ -124,8 +127,10 @@ def main():
     ap.add_argument("--force", action="store_true")
     ap.add_argument("-v", "--verbose", action="store_true")
     ap.add_argument("-j", "--jobs", type=int, default=8)
+    ap.add_argument("--extra", default="", help="extra hipcc flags for the kernels (tuning variants)")
+    ap.add_argument("--out", default=SO_PATH, help="output library (default eventgpt_amd/_C.so)")
     a = ap.parse_args()
-    print(build(a.force, a.verbose, a.jobs))
+    print(build(a.force, a.verbose, a.jobs, a.extra, a.out))
 
 
 if __name__ == "__main__":

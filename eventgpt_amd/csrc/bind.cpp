@@ -538,6 +538,17 @@ void decode_gemv(const Tensor& w, const Tensor& xin, const Tensor& y, bool accum
                      nullptr, 0.f, 0, (int)B, (int)N, (int)K, cur_stream());
 }
 
+// out_f32 [1,B,N] = W @ xin as raw fp32 sums: the local partial of a row-parallel projection,
+// summed over the ranks (and rounded once) by the all-reduce that follows
+void decode_gemv_partial(const Tensor& w, const Tensor& xin, const Tensor& out_f32) {
+  check_bf16(w, "w"); check_bf16(xin, "xin"); check_f32(out_f32, "out");
+  const int64_t B = xin.size(0), K = xin.size(1), N = w.size(0);
+  TORCH_CHECK(xin.dim() == 2 && w.size(1) == K && out_f32.numel() == B * N && N % 4 == 0 && K % 8 == 0);
+  TORCH_CHECK(B <= evgpt::gemv_max_batch() && B * K * 2 <= 96 * 1024);
+  evgpt::launch_gemv(bptr(w), bptr(xin), nullptr, nullptr, nullptr, nullptr, 0.f, 0, (int)B, (int)N, (int)K,
+                     cur_stream(), nullptr, out_f32.data_ptr<float>());
+}
+
 // h = silu(Wg rmsnorm(x)) * (Wu rmsnorm(x));  w_gate_up [2I,K] = [gate rows | up rows]
 void decode_mlp_up(const Tensor& w_gate_up, const Tensor& x, const Tensor& norm_w, double eps,
                    const Tensor& h) {
@@ -640,6 +651,7 @@ std::tuple<Tensor, Tensor> linear_argmax_partials(const Tensor& x, const Tensor&
 
 void gemm_force_config(int64_t cfg) { evgpt::gemm_force_config((int)cfg); }
 void gemm_force_splitk(int64_t sk) { evgpt::gemm_force_splitk((int)sk); }
+void gemv_force_ks(int64_t ks) { evgpt::gemv_force_ks((int)ks); }
 
 // ------------------------------------------------------------ event front end
 // x,y,p int32 [n]; returns uint8 [T,H,W,3].  mode 0: last event wins, 1: negative wins.
@@ -806,6 +818,8 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("clip_preprocess(Tensor img, Tensor hstart, Tensor hcount, Tensor hweight, Tensor vstart, Tensor vcount, Tensor vweight, int S, int resize_h, int resize_w, int top, int left, float[] mean, float[] stdv) -> Tensor", &clip_preprocess);
   m.def("gemm_force_config(int cfg) -> ()", &gemm_force_config);
   m.def("gemm_force_splitk(int sk) -> ()", &gemm_force_splitk);
+  m.def("gemv_force_ks(int ks) -> ()", &gemv_force_ks);
+  m.def("decode_gemv_partial(Tensor w, Tensor xin, Tensor(a!) out_f32) -> ()", &decode_gemv_partial);
   m.def("patchify(Tensor px, int P) -> Tensor", &patchify);
   m.def("vit_embed_ln(Tensor tok, Tensor cls, Tensor pos, Tensor w, Tensor b, float eps) -> Tensor", &vit_embed_ln);
   m.def("verify_accept(Tensor pval, Tensor pidx, Tensor draft, int G, Tensor(a!) out_tokens, Tensor(b!) step, Tensor(c!) pos, Tensor(d!) done, Tensor(e!) cur_token, Tensor(f!) result, int eos, Tensor embed, Tensor(g!) x) -> ()", &verify_accept);

@@ -20,7 +20,8 @@ void launch_w4_dequant(const unsigned char* packed, const float* absmax, const W
                        bf16_t* out, long long n_rows, int K, hipStream_t st);
 void launch_gemv(const bf16_t* W, const bf16_t* x, bf16_t* y, const bf16_t* bias,
                  const bf16_t* res, const bf16_t* norm_w, float eps, int act, int B, int N,
-                 int K, hipStream_t st, const W4Desc* w4 = nullptr);
+                 int K, hipStream_t st, const W4Desc* w4 = nullptr, float* y_f32 = nullptr);
+void gemv_force_ks(int ks);   // 0 = automatic; 1, 2 or 4 waves per 4-row unit (tuning runs)
 void launch_gemv_swiglu(const bf16_t* W_gate_up, const bf16_t* x, bf16_t* y,
                         const bf16_t* norm_w, float eps, int B, int inter, int K, hipStream_t st,
                         const W4Desc* w4 = nullptr);
@@ -119,6 +120,43 @@ void launch_reduce_rope_kv(const float* partial, int nslab, bf16_t* q_out, bf16_
                            bf16_t* v_cache, const float* cos_tab, const float* sin_tab,
                            const int* pos0, int B, int S, int Hq, int Hkv, int D, int l_max,
                            hipStream_t st);
+
+// ---- comm.hip (tensor-parallel collectives on peer-mapped buffers, vocab-parallel argmax)
+constexpr int COMM_MAX_RANKS = 8;       // slots per receive buffer
+constexpr int COMM_MAX_BLOCKS = 64;     // block regions per call
+constexpr int COMM_CHUNK_MAX = 4096;    // floats per region (one row of a 4096-wide model)
+// Receive buffer of one rank: float data[2][COMM_MAX_RANKS][COMM_MAX_BLOCKS][COMM_CHUNK_MAX]
+// and unsigned flag[2][COMM_MAX_RANKS][COMM_MAX_BLOCKS], both uncached device memory.
+constexpr long long COMM_DATA_FLOATS = 2ll * COMM_MAX_RANKS * COMM_MAX_BLOCKS * COMM_CHUNK_MAX;
+constexpr long long COMM_FLAG_WORDS = 2ll * COMM_MAX_RANKS * COMM_MAX_BLOCKS;
+struct CommState {            // lives in device memory, one per rank
+  float* data[COMM_MAX_RANKS];      // data[p]: rank p's receive buffer (peer-mapped; [rank] is mine)
+  unsigned* flag[COMM_MAX_RANKS];   // flag[p]: rank p's flag words
+  unsigned* epoch;                  // [COMM_MAX_BLOCKS] calls completed per block region (local)
+  unsigned* err;                    // [4]: timeouts, then epoch / peer / region of the last one (local)
+  int rank, world;
+  unsigned spin_limit;              // polls before a wait gives up
+};
+struct ARCall {
+  const CommState* cs;
+  const float* partial;       // [nslab][M][N] local partial sums
+  long long slab_stride;      // M*N
+  int nslab, M, N, chunk, bpr;
+  const bf16_t* res;          // [M][N] or null
+  bf16_t* x_out;              // [M][N] bf16(sum) + res, or null
+  const bf16_t* norm_w;       // [N]: RMSNorm of x_out into xn_out (only when a block owns a row)
+  bf16_t* xn_out;
+  float* sum_out;             // optional fp32 [M][N] reduced sum
+  float eps;
+};
+struct ARCallSet { ARCall c[COMM_MAX_RANKS]; };   // one per rank driven by this launch (1 in production)
+int comm_plan(int M, int N, int* chunk, int* bpr);   // blocks of a call, 0 if it does not fit
+void launch_oneshot_allreduce(const ARCallSet& calls, int n_virtual, int blocks, int nslab, int world,
+                              hipStream_t st);
+void launch_sum_slabs(const float* partial, int nslab, long long n, float* out, hipStream_t st);
+void launch_argmax_pair_local(const float* part_val, const int* part_idx, int B, int n_part,
+                              int index_offset, unsigned* pair, hipStream_t st);
+void launch_argmax_pair_select(const unsigned* pairs, int W, int B, int* token, hipStream_t st);
 
 // ---- attn_decode.hip
 void launch_attn_decode(const bf16_t* q, const bf16_t* k_cache, const bf16_t* v_cache,

@@ -31,7 +31,9 @@
 // table).  x is always staged in LDS in this mode (a lane needs 64 bytes of x per
 // 16 bytes of weights), XOR-swizzled so that the 64-byte lane stride is
 // conflict-free.
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "../evgpt_kernels.h"
@@ -50,6 +52,7 @@ struct GemvParams {
   int N, K;
   // E_STORE / E_RESIDUAL / E_SWIGLU
   bf16_t* y;             // [B][N_out]
+  float* yf;             // E_STORE: raw fp32 sums [B][N] instead of y (tensor-parallel partials)
   const bf16_t* res;     // [B][N]        (E_RESIDUAL; may alias y)
   const bf16_t* bias;    // [N] or null
   int act;
@@ -72,8 +75,18 @@ struct GemvParams {
   W4Code code;           // byte planes of the 16 bf16 codebook entries
 };
 
+// Measured on the 7B decode step (ms per token, same box): PRE/UNROLL/OCC = 1/4/4: 2.72,
+// 2/4/4: 3.13 (spills), 4/6/1: 2.90, 4/8/1: 2.94, 4/6/3: 4.39 (spills) -- prefetching more of
+// the first unit ahead of the norm, or issuing more than four iterations at once, costs
+// more in registers (fewer resident blocks) than it returns.
 #ifndef EVGPT_GEMV_PRE
 #define EVGPT_GEMV_PRE 1       // weight chunk-iterations requested ahead of the fused norm
+#endif
+#ifndef EVGPT_GEMV_UNROLL
+#define EVGPT_GEMV_UNROLL 4    // most chunk-iterations whose loads are all issued before the first use
+#endif
+#ifndef EVGPT_GEMV_OCC
+#define EVGPT_GEMV_OCC 4       // waves per SIMD a one-row bf16 kernel's register budget must admit
 #endif
 constexpr int R = 4;           // rows per unit
 constexpr int GEMV_WAVES = 4;  // waves per block
@@ -113,7 +126,7 @@ template <int B, int P, int E, int KS, int Q>
 // 4-bit: the expansion is VALU work that needs other waves to hide under, so the
 // register budget is capped for 4 waves per SIMD (the compiler otherwise hoists every
 // row's expansion and ends at 1-2)
-__global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : 1) void gemv_kernel(GemvParams p) {
+__global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : (B == 1 ? EVGPT_GEMV_OCC : (B == 2 ? 3 : 2))) void gemv_kernel(GemvParams p) {
   static_assert(KS == 1 || KS == 2 || KS == 4, "KS waves per unit");
   static_assert(E != E_LOGITS || KS == 1, "logits epilogue runs one wave per unit");
   constexpr int UPB = GEMV_WAVES / KS;  // units per block iteration
@@ -140,13 +153,40 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : 1) void gem
   const int n_ub = (n_units + UPB - 1) / UPB;
 
   // ---------------- prologue: normalise x into LDS (fused RMSNorm) ----------------
-  // The weights do not depend on x, so the first PRE chunk-iterations of this
-  // wave's first unit are requested before the norm: the HBM round trip of the
-  // first weight bytes then overlaps the reduction instead of following it.
+  // A wave's loads return in issue order, so the x / norm-weight chunks of the fused norm
+  // are requested FIRST and the weights right behind them: the weights do not depend on
+  // x, and with up to PRE chunk-iterations of this wave's first unit already in flight
+  // the HBM round trip of the weight bytes overlaps the reduction instead of following
+  // it (a launch whose blocks are all resident at once has nothing else to hide it).
   constexpr int PRE = Q ? 0 : EVGPT_GEMV_PRE;  // 4-bit: the registers go to the expansion
+  constexpr int XC = 2;  // x chunks a thread keeps in registers between the two norm passes
+  const bool fast_norm = (P == P_RMSNORM) && nchunk <= XC * GEMV_WAVES * 64;
+  constexpr int XB = Q ? 1 : B;   // 4-bit: one x row live at a time (registers go to the expansion)
+  u32x4_t nw[XC], xrow[XB][XC];
+  auto load_xrow = [&](int b, u32x4_t (&dst)[XC]) {
+#pragma unroll
+    for (int i = 0; i < XC; ++i) {
+      const int c = tid + i * GEMV_WAVES * 64;
+      dst[i] = load16(p.x + (static_cast<size_t>(b) * p.K + (c < nchunk ? c : 0) * 8));
+      if (c >= nchunk) dst[i] = u32x4_t{0, 0, 0, 0};
+    }
+  };
+  if constexpr (P == P_RMSNORM) {
+    if (fast_norm) {
+#pragma unroll
+      for (int i = 0; i < XC; ++i) {
+        const int c = tid + i * GEMV_WAVES * 64;
+        nw[i] = load16(p.norm_w + (c < nchunk ? c : 0) * 8);
+      }
+      if constexpr (!Q) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) load_xrow(b, xrow[b]);
+      }
+    }
+  }
   u32x4_t pre[PRE > 0 ? PRE : 1][R];
   float pre_sc[PRE > 0 ? PRE : 1][R];
-  if constexpr (STAGE) {
+  if constexpr (STAGE && PRE > 0) {
     const int u = blockIdx.x * UPB + ub_slot;
     int row[R];
     unit_rows<E>(p, u < n_units ? u : n_units - 1, row);
@@ -158,35 +198,24 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : 1) void gem
       for (int r = 0; r < R; ++r) {
         const int rr = row[r] < p.N ? row[r] : p.N - 1;
         pre[i][r] = load_stream16(Wb + static_cast<size_t>(rr) * row_bytes + static_cast<size_t>(cc) * 16);
-        if constexpr (Q)
-          pre_sc[i][r] = __builtin_nontemporal_load(p.absmax + static_cast<size_t>(rr) * nblk + (cc >> 1));
+        pre_sc[i][r] = 0.f;
       }
     }
   }
   if constexpr (P == P_RMSNORM) {
-    constexpr int XC = 2;  // x chunks a thread keeps in registers between the two passes
-    if (nchunk <= XC * GEMV_WAVES * 64) {
-      u32x4_t nw[XC];
-#pragma unroll
-      for (int i = 0; i < XC; ++i) {
-        const int c = tid + i * GEMV_WAVES * 64;
-        nw[i] = c < nchunk ? load16(p.norm_w + c * 8) : u32x4_t{0, 0, 0, 0};
-      }
+    if (fast_norm) {
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        u32x4_t xv[XC];
+        if constexpr (Q) load_xrow(b, xrow[0]);
+        const u32x4_t (&xr)[XC] = xrow[Q ? 0 : b];
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < XC; ++i) {
-          const int c = tid + i * GEMV_WAVES * 64;
-          xv[i] = c < nchunk ? load16(p.x + (static_cast<size_t>(b) * p.K + c * 8))
-                             : u32x4_t{0, 0, 0, 0};
+        for (int i = 0; i < XC; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float lo = bf16lo(xv[i][j]), hi = bf16hi(xv[i][j]);
+            const float lo = bf16lo(xr[i][j]), hi = bf16hi(xr[i][j]);
             ss += lo * lo + hi * hi;
           }
-        }
         ss = block_sum(ss, red);
         const float rstd = rsqrtf(ss / static_cast<float>(p.K) + p.eps);
 #pragma unroll
@@ -196,8 +225,8 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : 1) void gem
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             // HF order: round x*rstd to bf16, then multiply by the bf16 weight
-            const float lo = bf16_to_f32(f32_to_bf16(bf16lo(xv[i][j]) * rstd)) * bf16lo(nw[i][j]);
-            const float hi = bf16_to_f32(f32_to_bf16(bf16hi(xv[i][j]) * rstd)) * bf16hi(nw[i][j]);
+            const float lo = bf16_to_f32(f32_to_bf16(bf16lo(xr[i][j]) * rstd)) * bf16lo(nw[i][j]);
+            const float hi = bf16_to_f32(f32_to_bf16(bf16hi(xr[i][j]) * rstd)) * bf16hi(nw[i][j]);
             o[j] = pack_bf16x2(lo, hi);
           }
           if (c < nchunk) xs[b * nchunk + xs_slot<Q>(c)] = o;
@@ -302,7 +331,8 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : 1) void gem
       }
     }
 
-    auto consume = [&](const u32x4_t (&wv)[R], const float (&sc)[R], int c) {
+    // xg: this lane's x chunk per row, already in registers (no fused norm, bf16 weights)
+    auto consume = [&](const u32x4_t (&wv)[R], const float (&sc)[R], int c, const u32x4_t* xg) {
       if constexpr (Q) {
         u32x4_t xv[B][4];
 #pragma unroll
@@ -334,34 +364,87 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : 1) void gem
         for (int b = 0; b < B; ++b) {
           u32x4_t xv;
           if constexpr (P == P_RMSNORM) xv = xs[b * nchunk + c];
-          else xv = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+          else xv = xg[b];
 #pragma unroll
           for (int r = 0; r < R; ++r) acc[r][b] = dot8_bf16(wv[r], xv, acc[r][b]);
         }
       }
     };
     int c = c_begin + lane;
-    if constexpr (STAGE) {
+    // chunk-iterations of this wave's slice (wave-uniform: ks comes from the wave id)
+    int it_left = __builtin_amdgcn_readfirstlane((c_end - c_begin + 63) >> 6);
+    if constexpr (STAGE && PRE > 0) {
       if (ub == blockIdx.x) {  // the chunks requested ahead of the prologue
 #pragma unroll
         for (int i = 0; i < PRE; ++i) {
-          if (c < c_end) consume(pre[i], pre_sc[i], c);
+          if (c < c_end) consume(pre[i], pre_sc[i], c, nullptr);
           c += 64;
         }
+        it_left = it_left > PRE ? it_left - PRE : 0;
       }
     }
-    // bf16: 4 iterations (16 loads) in flight per lane; 4-bit: one iteration is already
-    // 2048 weights per row-quad and the expansion needs the registers
-#pragma unroll(Q ? 1 : 4)
-    for (; c < c_end; c += 64) {
-      u32x4_t wv[R];
-      float sc[R];
+    // Every load of up to UN chunk-iterations is issued before the first dot product: a
+    // slice of n iterations is one memory round trip when n <= UN (a loop unrolled by a
+    // fixed factor runs its remainder one dependent round trip per iteration, which for
+    // a 2- or 5-iteration slice was most of the kernel).  4-bit: one iteration is already
+    // 2048 weights per row-quad and the expansion needs the registers.
+    constexpr int UN = Q ? 1 : EVGPT_GEMV_UNROLL;
+    auto run = [&](auto it_tag) {
+      constexpr int IT = decltype(it_tag)::value;
+      u32x4_t wv[IT][R];
+      float sc[IT][R];
+      u32x4_t xg[IT][B];
+      int cc[IT];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        wv[r] = load_stream16(wp[r] + static_cast<size_t>(c) * 16);
-        if constexpr (Q) sc[r] = __builtin_nontemporal_load(sp[r] + (c >> 1));
+      for (int i = 0; i < IT; ++i) {
+        cc[i] = c + 64 * i < c_end ? c + 64 * i : c_end - 1;  // lanes past the slice re-read its last chunk
+        if constexpr (!STAGE) {
+#pragma unroll
+          for (int b = 0; b < B; ++b) xg[i][b] = load16(p.x + (static_cast<size_t>(b) * p.K + cc[i] * 8));
+        }
       }
-      consume(wv, sc, c);
+#pragma unroll
+      for (int i = 0; i < IT; ++i)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          wv[i][r] = load_stream16(wp[r] + static_cast<size_t>(cc[i]) * 16);
+          if constexpr (Q) sc[i][r] = __builtin_nontemporal_load(sp[r] + (cc[i] >> 1));
+          else sc[i][r] = 0.f;
+        }
+#pragma unroll
+      for (int i = 0; i < IT; ++i)
+        if (c + 64 * i < c_end) consume(wv[i], sc[i], c + 64 * i, xg[i]);
+      c += 64 * IT;
+    };
+    if constexpr (Q) {
+      // 4-bit: one iteration at a time in a plain per-lane loop (the expansion of one
+      // iteration already fills the register budget of 4 waves per SIMD)
+      for (; c < c_end; c += 64) {
+        u32x4_t wv[R];
+        float sc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          wv[r] = load_stream16(wp[r] + static_cast<size_t>(c) * 16);
+          sc[r] = __builtin_nontemporal_load(sp[r] + (c >> 1));
+        }
+        consume(wv, sc, c, nullptr);
+      }
+      it_left = 0;
+    }
+    while (it_left > 0) {
+      // n <= UN: one shot; n <= 2 UN: two even shots; else UN at a time
+      const int n = it_left <= UN ? it_left : (it_left <= 2 * UN ? (it_left + 1) >> 1 : UN);
+      switch (n) {
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: if constexpr (UN >= 2) run(std::integral_constant<int, 2>{}); break;
+        case 3: if constexpr (UN >= 3) run(std::integral_constant<int, 3>{}); break;
+        case 4: if constexpr (UN >= 4) run(std::integral_constant<int, 4>{}); break;
+        case 5: if constexpr (UN >= 5) run(std::integral_constant<int, 5>{}); break;
+        case 6: if constexpr (UN >= 6) run(std::integral_constant<int, 6>{}); break;
+        case 7: if constexpr (UN >= 7) run(std::integral_constant<int, 7>{}); break;
+        default: if constexpr (UN >= 8) run(std::integral_constant<int, 8>{}); break;
+      }
+      it_left -= n;
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -411,6 +494,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : 1) void gem
           for (int r = 0; r < R; ++r) {
             if (row[r] < p.N) {
               float v = acc[r][b];
+              if (p.yf) { p.yf[static_cast<size_t>(b) * p.N + row[r]] = v; continue; }
               if (p.bias) v += bf16_to_f32(p.bias[row[r]]);
               v = apply_act(v, p.act);
               p.y[static_cast<size_t>(b) * p.N + row[r]] = f32_to_bf16(v);
@@ -503,9 +587,33 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : 1) void gem
   }
 }
 
+static int g_forced_ks = 0;
+void gemv_force_ks(int ks) { g_forced_ks = ks; }   // 0 = automatic; for tuning runs
+
+// EVGPT_GEMV_KS="NxK:ks,NxK:ks" overrides the choice for single shapes (tuning runs)
+static int env_ks(int N, int K) {
+  static const char* e = getenv("EVGPT_GEMV_KS");
+  if (!e) return 0;
+  for (const char* s = e; *s;) {
+    int n = 0, k = 0, ks = 0, used = 0;
+    if (sscanf(s, "%dx%d:%d%n", &n, &k, &ks, &used) != 3) break;
+    if (n == N && k == K) return ks;
+    s += used;
+    if (*s == ',') ++s;
+  }
+  return 0;
+}
+
 // waves-per-unit so that the launch has >= ~6000 waves (24 per CU)
-static int pick_ks(int N) {
+static int pick_ks(int N, int K) {
+  if (g_forced_ks == 1 || g_forced_ks == 2 || g_forced_ks == 4) return g_forced_ks;
+  const int ek = env_ks(N, K);
+  if (ek == 1 || ek == 2 || ek == 4) return ek;
   const int units = (N + R - 1) / R;
+  // a wave's slice of 2048 weights per row is exactly UNROLL(4) iterations of one round trip:
+  // a 4096-deep projection with few rows (o_proj) takes 2 waves per unit, not 4 (measured
+  // 2.86 vs 2.90 ms per 7B token); deeper ones (down_proj, 11008) keep 4
+  if (K <= 4096 && units * 2 >= 2048 && units < 3000) return 2;
   if (units >= 6000) return 1;
   if (units >= 3000) return 2;
   return 4;
@@ -557,14 +665,14 @@ static void launch_b(const GemvParams& p, int B, hipStream_t st) {
     // work (and the share of a block's prologue) comparable; measured on the 7B decode
     // step: 2.12 ms with the bf16 choice, 1.92 ms with half (EVGPT_W4_KS_SHIFT to tune)
     static const int shift = [] { const char* e = getenv("EVGPT_W4_KS_SHIFT"); return e ? atoi(e) : 1; }();
-    int ks = pick_ks(p.N) >> shift;
+    int ks = pick_ks(p.N, p.K) >> shift;
     switch (ks < 1 ? 1 : ks) {
       case 1: launch_bk<P, E, 1, 1>(p, B, st); break;
       case 2: launch_bk<P, E, 2, 1>(p, B, st); break;
       default: launch_bk<P, E, 4, 1>(p, B, st); break;
     }
   } else {
-    switch (pick_ks(p.N)) {
+    switch (pick_ks(p.N, p.K)) {
       case 1: launch_bk<P, E, 1, 0>(p, B, st); break;
       case 2: launch_bk<P, E, 2, 0>(p, B, st); break;
       default: launch_bk<P, E, 4, 0>(p, B, st); break;
@@ -584,9 +692,10 @@ static void set_w4(GemvParams& p, const W4Desc* w4) {
 
 void launch_gemv(const bf16_t* W, const bf16_t* x, bf16_t* y, const bf16_t* bias,
                  const bf16_t* res, const bf16_t* norm_w, float eps, int act, int B, int N,
-                 int K, hipStream_t st, const W4Desc* w4) {
+                 int K, hipStream_t st, const W4Desc* w4, float* y_f32) {
   GemvParams p{};
   set_w4(p, w4);
+  p.yf = y_f32;
   p.W = W; p.x = x; p.y = y; p.bias = bias; p.res = res; p.norm_w = norm_w; p.eps = eps;
   p.act = act; p.N = N; p.K = K;
   if (res) {

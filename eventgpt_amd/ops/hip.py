@@ -12,7 +12,10 @@ from typing import Optional
 
 import torch
 
-_SO = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_C.so")
+# EVGPT_SO picks another build of the same sources (a tuning variant linked by
+# ``python -m eventgpt_amd.build --extra ... --out ...``)
+_SO = os.environ.get("EVGPT_SO") or os.path.join(
+    os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_C.so")
 if not os.path.exists(_SO):
     raise RuntimeError(
         f"{_SO} not found: the HIP extension is not built. Run `python -m eventgpt_amd.build` "

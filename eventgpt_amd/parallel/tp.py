@@ -18,9 +18,10 @@ Two executions of the same sharding:
   * ``TensorParallelDecoder`` — nn.Module path through ``eventgpt_amd.ops``; runs
     anywhere (CPU + gloo in the tests) and is the correctness oracle;
   * ``TensorParallelEngine`` — the serving engine (``runtime.engine``) on shards:
-    fused GEMV kernels for batch <= 4, MFMA GEMM (split-K for M <= 32) for the
-    bs=32 batched-decode configuration, static KV cache of the local heads,
-    greedy token selection by gathering per-rank argmax partials.
+    fused GEMV kernels for batch <= 3, split-K MFMA GEMM with fused consumers up to
+    32 rows (the bs=32 batched-decode configuration), static KV cache of the local
+    heads, all-reduce fused with residual (+ norm), greedy token selection by
+    gathering one (max, index) pair per row and rank.
 
 The reference has no model parallelism (its only process group is a
 world-size-1 NCCL init demanded by a third-party model,
@@ -193,30 +194,73 @@ class TensorParallelDecoder(nn.Module):
 
 
 # ------------------------------------------------------------------- engine path
+def _host_collective(fn, t: torch.Tensor, *a, **kw):
+    """Run a collective on a host copy of ``t`` (gloo only ever sees CPU tensors)."""
+    host = t.cpu()
+    fn(host, *a, **kw)
+    t.copy_(host)
+    return t
+
+
 class TensorParallelEngine(GenerationEngine):
     """``GenerationEngine`` over weight shards, for any batch size.
 
-    ``group=None`` (or a world of one) gives the plain batched engine — the same
-    code path minus the collectives — which is how it is exercised on one GPU.
+    ``group=None`` (or a world of one) gives the plain batched engine -- the same code path
+    minus the collectives -- which is how it is exercised on one GPU.
+
+    The sharded engine keeps every fusion of the single-GPU one.  Row-parallel projections
+    (``o_proj``, ``down_proj``) stop at fp32 partial sums; the collective sits between those
+    and the residual add:
+
+      * up to 3 rows: the weight-streaming GEMV writes raw fp32 sums, the all-reduce adds
+        the residual into the stream, and the next GEMV's prologue applies the RMSNorm;
+      * 4..32 rows: the split-K GEMM leaves its slabs, and the all-reduce launch sums slabs
+        and ranks and applies residual + the next RMSNorm (``reduce_residual_norm`` with a
+        collective inside);
+      * more rows (prefill): MFMA GEMMs with a bf16 all-reduce of the ``[S, H]`` product.
+
+    ``allreduce``: ``"rccl"`` (library collective, the default), ``"oneshot"`` (peer-mapped
+    push all-reduce, ``parallel/comm.py``) or ``"auto"`` (one-shot if its start-up self-test
+    against RCCL passes).  Greedy selection gathers 8 bytes per row and rank.
     """
 
-    def __init__(self, model, group=None, max_len: int = 2048, max_batch: int = 1, **kw):
+    def __init__(self, model, group=None, max_len: int = 2048, max_batch: int = 1,
+                 allreduce: Optional[str] = None, **kw):
         self._group_arg = group
-        if (group is not None and dist.is_initialized() and dist.get_world_size(group) > 1
-                and dist.get_backend(group) == "gloo"):
+        self._gloo = bool(group is not None and dist.is_initialized() and dist.get_world_size(group) > 1
+                          and dist.get_backend(group) == "gloo")
+        if self._gloo:
             kw["use_graph"] = False     # gloo collectives go through host copies: nothing to capture
         if kw.get("weight_format", "bf16") != "bf16":
             raise NotImplementedError("the batched / tensor-parallel engine runs bf16 weights; 4-bit weights "
                                       "are a GenerationEngine (single stream, <= 3 rows) format")
         super().__init__(model, max_len=max_len, max_batch=max_batch, **kw)
-        if self.tp_world > 1:   # samplers read the gathered, full-vocabulary rows
-            self.logits = torch.zeros(self.B, self.v_total, dtype=torch.float32, device=self.device)
+        dev = self.device
+        self.oneshot = None
+        self.allreduce_kind = "none"
+        if self.tp_world > 1:
+            from . import comm
+            # samplers read the gathered, full-vocabulary rows
+            self.logits = torch.zeros(self.B, self.v_total, dtype=torch.float32, device=dev)
+            self._part = torch.zeros(1, max(self.B, self.gemv_rows), self.H, dtype=torch.float32, device=dev)
+            self._pair = torch.zeros(self.B, 2, dtype=torch.int32, device=dev)
+            self._pairs = torch.zeros(self.tp_world, self.B, 2, dtype=torch.int32, device=dev)
+            mode = (allreduce or comm.allreduce_mode()).lower()
+            self.allreduce_kind = "gloo" if self._gloo else "rccl"
+            # "oneshot" on a gloo group is the two-processes-on-one-GPU test set-up: gloo only
+            # bootstraps (handle exchange, barrier); "auto" needs the library collective to
+            # check against, so it is an RCCL-group mode
+            if mode == "oneshot" or (mode == "auto" and not self._gloo):
+                ar = comm.OneShotAllReduce(self.tp_group, dev)
+                if mode == "oneshot" or ar.self_test():
+                    self.oneshot, self.allreduce_kind = ar, "oneshot"
+                else:
+                    ar.close()
 
     def _setup_parallel(self) -> None:
         g = self._group_arg
         if g is not None and dist.is_initialized() and dist.get_world_size(g) > 1:
             self.tp_group, self.tp_world, self.tp_rank = g, dist.get_world_size(g), dist.get_rank(g)
-        cfg = self.cfg
         self.Hq_full, self.Hkv_full, self.I_full = self.Hq, self.Hkv, self.I
         self.Hq //= self.tp_world
         self.Hkv //= self.tp_world
@@ -237,17 +281,62 @@ class TensorParallelEngine(GenerationEngine):
                     if p.ndim == 2:
                         p.data = p.data.new_empty(0)
         self.final_norm = model.model.norm.weight.data
-        self.lm_head, self.v0 = shard_vocab(model.lm_head.weight.data, self.tp_rank, self.tp_world)
+        shard, self.v0 = shard_vocab(model.lm_head.weight.data, self.tp_rank, self.tp_world)
         self.v_total = model.lm_head.weight.shape[0]
+        self.v_per = shard.shape[0]
+        # only the rows that exist: the last rank's zero padding never enters an argmax
+        self.lm_head = shard[:max(1, min(self.v_per, self.v_total - self.v0))]
         self.embed = model.model.embed_tokens.weight.data
 
-    # ------------------------------------------------------------------ layers
+    # -------------------------------------------------------------- collectives
     def _reduce(self, t: torch.Tensor) -> torch.Tensor:
         return _all_reduce(t, self.tp_group)
 
+    def _allreduce_f32(self, t: torch.Tensor) -> torch.Tensor:
+        """Library all-reduce of an fp32 tensor in place."""
+        if self._gloo:
+            return _host_collective(dist.all_reduce, t, group=self.tp_group)
+        dist.all_reduce(t, group=self.tp_group)
+        return t
+
+    def _reduce_residual_norm(self, partial, x, norm_w):
+        if self.tp_world == 1:
+            return super()._reduce_residual_norm(partial, x, norm_w)
+        raw = self.raw
+        M, N = partial.shape[1], partial.shape[2]
+        if self.oneshot is not None:
+            x_out = torch.empty(M, N, dtype=torch.bfloat16, device=self.device)
+            fuse_norm = norm_w is not None and M > 3 and N <= 4096
+            xn = torch.empty_like(x_out) if fuse_norm else None
+            if self.oneshot.reduce(partial, res=x.view(M, N), x_out=x_out, norm_w=norm_w if fuse_norm else None,
+                                   xn_out=xn, eps=self.eps):
+                if norm_w is not None and not fuse_norm:
+                    xn = raw.rmsnorm(x_out, norm_w, self.eps)
+                return x_out, (xn if norm_w is not None else x_out.new_empty(0))
+        total = raw.sum_slabs(partial) if partial.shape[0] > 1 else partial
+        if total.data_ptr() == partial.data_ptr():
+            total = partial.clone()          # the caller's slab tensor is not ours to overwrite
+        self._allreduce_f32(total)
+        return raw.reduce_residual_norm(total, x.view(M, N), norm_w, self.eps, None)
+
+    def _gemv_residual(self, l, name: str, xin, y) -> None:
+        """``y += W[name] @ xin`` summed over the ranks (rows <= 3: weight-streaming GEMV)."""
+        if self.tp_world == 1:
+            return super()._gemv_residual(l, name, xin, y)
+        rows = xin.shape[0]
+        part = self._part[:, :rows]
+        self.raw.decode_gemv_partial(getattr(l, name), xin, part)
+        if self.oneshot is not None and self.oneshot.reduce(part, res=y, x_out=y, eps=self.eps):
+            return
+        self._allreduce_f32(part)
+        self.raw.reduce_residual_norm(part, y, None, self.eps, y)
+
+    # ------------------------------------------------------------------ layers
     def _forward_rows(self, embeds, batch, pos0):
         raw = self.raw
         S = embeds.shape[0]
+        if self._gemv_rows_ok(S):
+            return self._forward_rows_gemv(embeds, batch, pos0)
         if self._few_rows_ok(S):
             return self._forward_rows_fused(embeds, batch, pos0)
         x = embeds.to(torch.bfloat16).contiguous().view(1, S, self.H)
@@ -268,25 +357,15 @@ class TensorParallelEngine(GenerationEngine):
 
     def _layers_step(self) -> None:
         raw = self.raw
-        lead = self.tp_rank == 0
         if self.B <= 3:     # measured: the GEMV holds up to 3 rows (3.09 / 3.75 ms), 4 rows are faster as a GEMM
-            for l in self.layers:
-                raw.decode_qkv(self.x, l.norm1, l.w_qkv, self.q, l.k_cache, l.v_cache, self.cos,
-                               self.sin, self.pos, self.eps, self.Hq, self.Hkv, self.D)
-                raw.decode_attn(self.q, l.k_cache, l.v_cache, self.attn, self.part_o, self.part_ml,
-                                self.pos, self.nsplit, self.scale)
-                raw.decode_gemv(l.w_o, self.attn, self.x, lead)
-                self._reduce(self.x)
-                raw.decode_mlp_up(l.w_gate_up, self.x, l.norm2, self.eps, self.h)
-                raw.decode_gemv(l.w_down, self.h, self.x, lead)
-                self._reduce(self.x)
-            return
+            return super()._layers_step()
         # batched decode (e.g. 32 streams): M = B rows through the MFMA GEMM
         B = self.B
         x = self.x
         if self._few_rows_ok(B):
-            # one engine, <= 32 streams: the split-K consumers carry RoPE/cache append,
-            # residual + next norm and SwiGLU (no separate launches for them)
+            # <= 32 streams: the split-K consumers carry RoPE/cache append, residual + next
+            # norm and SwiGLU (no separate launches for them); with several ranks the
+            # residual consumer is also the all-reduce
             n = len(self.layers)
             xn = raw.rmsnorm(x, self.layers[0].norm1, self.eps)
             for i, l in enumerate(self.layers):
@@ -294,13 +373,13 @@ class TensorParallelEngine(GenerationEngine):
                                    self.cos, self.sin, self.pos, B, 1, self.Hq, self.Hkv, self.D)
                 raw.decode_attn(self.q, l.k_cache, l.v_cache, self.attn, self.part_o, self.part_ml,
                                 self.pos, self.nsplit, self.scale)
-                x, xn = raw.reduce_residual_norm(raw.linear_partial(self.attn, l.w_o), x, l.norm2,
-                                                 self.eps, None)
+                x, xn = self._reduce_residual_norm(raw.linear_partial(self.attn, l.w_o), x, l.norm2)
                 h = raw.reduce_swiglu(raw.linear_partial(xn, l.w_gate_up))
                 nxt = self.layers[i + 1].norm1 if i + 1 < n else None
-                x, xn = raw.reduce_residual_norm(raw.linear_partial(h, l.w_down), x, nxt, self.eps, None)
+                x, xn = self._reduce_residual_norm(raw.linear_partial(h, l.w_down), x, nxt)
             self.x.copy_(x)
             return
+        lead = self.tp_rank == 0
         for l in self.layers:
             qkv = raw.linear(raw.rmsnorm(x, l.norm1, self.eps), l.w_qkv, None, None, 0, False)
             raw.prefill_rope_kv(qkv.view(B, 1, -1), self.q.view(B, 1, -1), l.k_cache, l.v_cache,
@@ -312,26 +391,50 @@ class TensorParallelEngine(GenerationEngine):
             x = self._reduce(raw.linear(raw.swiglu(gu), l.w_down, None, x if lead else None, 0, False))
         self.x.copy_(x)
 
+    # ------------------------------------------------------------------ head
+    def _gather_pairs(self) -> None:
+        """``self._pair [B,2]`` of every rank -> ``self._pairs [W,B,2]`` (8 bytes per row and rank)."""
+        if self._gloo:
+            host = self._pair.cpu()
+            bufs = [torch.empty_like(host) for _ in range(self.tp_world)]
+            dist.all_gather(bufs, host, group=self.tp_group)
+            self._pairs.copy_(torch.stack(bufs))
+        else:
+            dist.all_gather_into_tensor(self._pairs.view(-1), self._pair.view(-1), group=self.tp_group)
+
     def _logits_and_commit(self, greedy: bool, want_logits: bool = False) -> None:
         raw = self.raw
-        hn = raw.rmsnorm(self.x, self.final_norm, self.eps)
-        logits = raw.linear(hn, self.lm_head, None, None, 0, True)          # fp32 [B, V_local]
-        n_valid = min(self.lm_head.shape[0], max(self.v_total - self.v0, 0))
-        if n_valid < logits.shape[1]:
-            logits[:, n_valid:] = float("-inf")
-        if not greedy or want_logits:
+        full = (not greedy) or want_logits
+        if self.tp_world == 1 and self.B <= int(raw.gemv_max_batch()):
+            return super()._logits_and_commit(greedy, want_logits)
+        if full:
+            hn = raw.rmsnorm(self.x, self.final_norm, self.eps)
+            local = raw.linear(hn, self.lm_head, None, None, 0, True)           # fp32 [B, V_local]
             if self.tp_world > 1:
-                # a sampler needs every rank's vocabulary shard: gather them in rank order
-                self.logits.copy_(gather_vocab_shards(logits, self.v_total, self.tp_group))
+                pad = self.v_per - local.shape[1]
+                if pad:
+                    local = torch.nn.functional.pad(local, (0, pad), value=float("-inf"))
+                self.logits.copy_(gather_vocab_shards(local, self.v_total, self.tp_group))
             else:
-                self.logits.copy_(logits[:, :self.logits.shape[1]])
-        if greedy:
-            # own argmax kernel + gather: graph-safe (no library reduction in the capture)
-            idx = raw.argmax_rows(logits)
-            val = logits.gather(1, idx[:, None])[:, 0]
-            tok = distributed_argmax(val, idx + self.v0, self.tp_group)
-            self.sampled.copy_(tok.to(torch.int32))
-            self._commit_sampled()
+                self.logits.copy_(local[:, :self.logits.shape[1]])
+        if not greedy:
+            return
+        # per-row argmax partials of this rank's rows, never the logits themselves
+        if self.B <= int(raw.gemv_max_batch()):
+            raw.decode_logits(self.lm_head, self.x, self.final_norm, self.eps, None, self.part_val, self.part_idx)
+            pv, pi, n_part = self.part_val, self.part_idx, self.n_part
+        else:
+            hn = raw.rmsnorm(self.x, self.final_norm, self.eps)
+            pv, pi = raw.linear_argmax_partials(hn, self.lm_head, None)
+            n_part = pv.shape[1]
+        if self.tp_world == 1:
+            raw.commit_token(pv, pi, n_part, None, self.embed, self.x, self.out_tokens, self.step, self.pos,
+                             self.done, self.cur_token, self.eos, self.active)
+            return
+        raw.argmax_pair_local(pv, pi, self.B, n_part, self.v0, self._pair)
+        self._gather_pairs()
+        raw.argmax_pair_select(self._pairs, self.tp_world, self.B, self.sampled)
+        self._commit_sampled()
 
     # ----------------------------------------------------------------- batching
     @torch.no_grad()

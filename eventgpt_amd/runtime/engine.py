@@ -268,7 +268,7 @@ class GenerationEngine:
 
     def _gemv_rows_ok(self, rows: int) -> bool:
         cap = int(self.raw.gemv_w4_max_batch() if self.w4 else self.raw.gemv_max_batch())
-        return 1 <= rows <= min(self.gemv_rows, cap) and self.tp_world == 1
+        return 1 <= rows <= min(self.gemv_rows, cap)
 
     def _forward_rows_gemv(self, embeds: torch.Tensor, batch: int, pos0: torch.Tensor) -> torch.Tensor:
         raw = self.raw
@@ -317,8 +317,14 @@ class GenerationEngine:
     fused_rows = 32
 
     def _few_rows_ok(self, rows: int) -> bool:
-        return (3 < rows <= self.fused_rows and self.tp_world == 1 and self.H % 64 == 0
+        return (3 < rows <= self.fused_rows and self.H % 64 == 0
                 and self.I % 64 == 0 and (self.Hq * self.D) % 64 == 0)
+
+    def _reduce_residual_norm(self, partial, x, norm_w):
+        """``(x + bf16(sum of the split-K slabs), RMSNorm of that * norm_w)`` of a row-parallel
+        projection's partials ``[nslab, M, N]``.  A tensor-parallel engine also sums over the
+        ranks here: the collective sits between the slab sum and the residual add."""
+        return self.raw.reduce_residual_norm(partial, x, norm_w, self.eps, None)
 
     def _forward_rows_fused(self, embeds: torch.Tensor, batch: int, pos0: torch.Tensor) -> torch.Tensor:
         raw = self.raw
@@ -334,11 +340,11 @@ class GenerationEngine:
             raw.reduce_rope_kv(raw.linear_partial(xn, self._w(l, "w_qkv")), q, kc, vc, self.cos, self.sin, pos0,
                                1, S, self.Hq, self.Hkv, self.D)
             raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
-            x, xn = raw.reduce_residual_norm(raw.linear_partial(o.view(S, self.Hq * self.D), self._w(l, "w_o")),
-                                             x, l.norm2, self.eps, None)
+            x, xn = self._reduce_residual_norm(raw.linear_partial(o.view(S, self.Hq * self.D), self._w(l, "w_o")),
+                                               x, l.norm2)
             h = raw.reduce_swiglu(raw.linear_partial(xn, self._w(l, "w_gate_up")))
             nxt = self.layers[i + 1].norm1 if i + 1 < n else None
-            x, xn = raw.reduce_residual_norm(raw.linear_partial(h, self._w(l, "w_down")), x, nxt, self.eps, None)
+            x, xn = self._reduce_residual_norm(raw.linear_partial(h, self._w(l, "w_down")), x, nxt)
         return x.view(1, S, self.H)
 
     def _forward_rows(self, embeds: torch.Tensor, batch: int, pos0: torch.Tensor) -> torch.Tensor:
@@ -482,14 +488,23 @@ class GenerationEngine:
     def _capture_or_eager(self, fn):
         """``_capture`` that degrades to eager stepping when the step cannot be captured
         (e.g. a collective backend that does not record into graphs): warns once, turns
-        graphs off for this engine and returns None."""
+        graphs off for this engine, records the reason in ``graph_fallback`` (benchmarks
+        report it, so an eager run cannot pass for a captured one) and returns None."""
         try:
             return self._capture(fn)
         except RuntimeError as e:
             import warnings
             warnings.warn(f"decode step could not be captured into a HIP graph ({e}); running eagerly")
             self.use_graph = False
+            self.graph_fallback = str(e)[:200]
             return None
+
+    graph_fallback: Optional[str] = None
+
+    @property
+    def graph_captured(self) -> bool:
+        """True when decode steps replay a captured graph (not the eager fallback)."""
+        return bool(self.use_graph and (self._graph_greedy or self._graph_logits is not None))
 
     def ensure_graphs(self, eos_token_id: Optional[int] = None, greedy: bool = True) -> None:
         """Capture the decode graph for this EOS id now, if it is not captured yet.

@@ -1,5 +1,11 @@
 """Worker for the GPU tensor-parallel engine test: two ranks share GPU 0, the process
-group is gloo (host tensors only), graphs are off (a host copy cannot be captured)."""
+group is gloo (host tensors only), graphs are off (a host copy cannot be captured).
+
+Runs the sharded engine in four configurations -- 2 and 6 streams (the weight-streaming
+GEMV path and the split-K GEMM + fused-consumer path), each with the library all-reduce
+(gloo through host copies) and with the one-shot push all-reduce over IPC-mapped buffers
+(two processes, one GPU: real ``hipIpcMemHandle`` exchange, every device wait bounded) --
+and compares each against the unsharded engine on the same prompts."""
 import json
 import os
 import sys
@@ -13,16 +19,10 @@ from eventgpt_amd.models import EventChatConfig, EventChatModel  # noqa: E402
 from eventgpt_amd.parallel.dist import init_distributed, shutdown  # noqa: E402
 from eventgpt_amd.parallel.tp import TensorParallelEngine  # noqa: E402
 
+cos = torch.nn.functional.cosine_similarity
 
-def main(out_path):
-    info = init_distributed(backend="gloo", use_gpu=True)
-    dev = info.device
-    cfg = EventChatConfig(vocab_size=515, hidden_size=512, intermediate_size=1408, num_hidden_layers=2,
-                          num_attention_heads=4, max_position_embeddings=512)
-    model = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=3)
-    B = 2
-    prompts = [(torch.randn(20 + 3 * b, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(b))
-                * 0.5).to(torch.bfloat16) for b in range(B)]
+
+def reference(model, prompts):
     single = model.engine(max_len=256, max_new_tokens=32, use_graph=False)
     want, want_x = [], []
     for p in prompts:
@@ -35,12 +35,15 @@ def main(out_path):
         single._logits_and_commit(greedy=True)
         want_x.append(xs)
         want.append(single.generate(p, 8, eos_token_id=-1).tolist())
-    print(f"rank {info.rank}: single-engine reference done", flush=True)
-    eng = TensorParallelEngine(model, dist.group.WORLD, max_len=256, max_batch=B, max_new_tokens=32,
-                               use_graph=False)
+    return want, want_x
+
+
+def run_config(model_fn, info, prompts, want_x, allreduce):
+    B = len(prompts)
+    eng = TensorParallelEngine(model_fn(), dist.group.WORLD, max_len=256, max_batch=B, max_new_tokens=32,
+                               use_graph=False, allreduce=allreduce)
     eng.eos = -1
     eng.prefill_batch(prompts)
-    cos = torch.nn.functional.cosine_similarity
     first_tok = [int(eng.out_tokens[b, 0]) for b in range(B)]
     c0 = [float(cos(eng.x[b].float(), want_x[b][0], dim=0)) for b in range(B)]
     eng._layers_step()
@@ -53,14 +56,41 @@ def main(out_path):
     # sampling path: every rank must hold the same full-vocabulary logits row
     eng._logits_and_commit(greedy=False)
     row = eng.logits[0].cpu()
+    timeouts = 0
+    if eng.oneshot is not None:
+        timeouts = int(eng.oneshot.buf.err[0].item())
     rows = [None] * info.world
     dist.all_gather_object(rows, row.tolist())
     gathered = [None] * info.world
-    dist.all_gather_object(gathered, got)
+    dist.all_gather_object(gathered, (got, timeouts))
+    res = {"ranks": [g[0] for g in gathered], "timeouts": [g[1] for g in gathered], "first_tok": first_tok,
+           "cos_prefill": c0, "cos_step": c1, "heads_local": eng.Hq, "i_local": eng.I,
+           "logits_width": int(eng.logits.shape[1]), "logits_equal": all(r == rows[0] for r in rows),
+           "allreduce_kind": eng.allreduce_kind}
+    if eng.oneshot is not None:
+        eng.oneshot.close()
+    return res
+
+
+def main(out_path):
+    info = init_distributed(backend="gloo", use_gpu=True)
+    dev = info.device
+    cfg = EventChatConfig(vocab_size=515, hidden_size=512, intermediate_size=1408, num_hidden_layers=2,
+                          num_attention_heads=4, max_position_embeddings=512)
+    model_fn = lambda: EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=3)   # noqa: E731
+    out = {}
+    for B in (2, 6):
+        prompts = [(torch.randn(20 + 3 * b, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(b))
+                    * 0.5).to(torch.bfloat16) for b in range(B)]
+        want, want_x = reference(model_fn(), prompts)
+        print(f"rank {info.rank}: single-engine reference for {B} streams done", flush=True)
+        for ar in ("rccl", "oneshot"):
+            print(f"rank {info.rank}: {B} streams, allreduce={ar}", flush=True)
+            res = run_config(model_fn, info, prompts, want_x, ar)
+            res["want"] = want
+            out[f"b{B}_{ar}"] = res
     if info.rank == 0:
-        json.dump({"want": want, "ranks": gathered, "first_tok": first_tok, "cos_prefill": c0, "cos_step": c1, "heads_local": eng.Hq, "i_local": eng.I,
-                   "logits_width": int(eng.logits.shape[1]),
-                   "logits_equal": all(r == rows[0] for r in rows)}, open(out_path, "w"))
+        json.dump(out, open(out_path, "w"))
     shutdown()
 
 

@@ -1,0 +1,54 @@
+"""bench.py as the driver invokes it: ``--gpus N`` without a torchrun environment must start N
+ranks (not silently run one), and a torchrun environment must be honoured as is.  The probe
+mode exercises the real launch path -- subprocess -> torch.distributed.run -> N ranks ->
+rendezvous -> an all-reduce -- on CPU (gloo), without touching a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("n", [2, 4])
+def test_gpus_flag_launches_n_ranks(n):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--model", "small", "--probe"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # exactly one JSON line, from rank 0
+    got = json.loads(lines[0])
+    assert got["n_gpus"] == n and got["rccl_world_size"] == n and got["requested"] == n
+    assert got["scaling"] == "strong"           # tensor-parallel is the multi-GPU default
+
+
+@pytest.mark.timeout(120)
+def test_torchrun_environment_is_honoured():
+    """The driver's own launch shape: torchrun starts the ranks, bench.py must not nest another job."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29571", BENCH, "--gpus", "2", "--probe"]
+    r = subprocess.run(cmd, env=_clean_env(), capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_single_gpu_default_does_not_launch():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args([])
+    assert a.gpus == 1 and a.parallelism == "tp" and a.batch == 1
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "5"], 29999)
+    assert "--nproc-per-node=8" in cmd and cmd[-4:] == ["--gpus", "8", "--steps", "5"]
+    assert "127.0.0.1" in cmd

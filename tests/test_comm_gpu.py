@@ -1,0 +1,170 @@
+"""One-shot all-reduce (csrc/kernels/comm.hip) on ONE GPU: W virtual ranks driven by a single
+launch (every block co-resident), checked against a plain fp32 sum; graph replays; the
+bounded wait's give-up path forced from the host; the vocab-parallel argmax pair kernels."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(partials, res, norm_w, eps):
+    total = torch.zeros_like(partials[0][0])
+    for p in partials:                      # rank order, slabs first: the kernel's order
+        total = total + p.sum(0)
+    x = total.to(torch.bfloat16).float() + (res.float() if res is not None else 0.0)
+    x = x.to(torch.bfloat16)
+    xn = None
+    if norm_w is not None:
+        xf = x.float()
+        xn = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(torch.bfloat16).float() * norm_w.float()
+        xn = xn.to(torch.bfloat16)
+    return total, x, xn
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("shape", [(1, 4096, 1), (3, 4096, 2), (6, 4096, 4), (16, 4096, 3), (1, 11008, 1),
+                                   (5, 1024, 8), (2, 512, 1)])
+def test_oneshot_allreduce_matches_sum(dev, world, shape):
+    from eventgpt_amd.parallel.comm import VirtualGroup, plan
+    M, N, ns = shape
+    blocks, chunk, bpr = plan(M, N)
+    vg = VirtualGroup(world, dev)
+    g = torch.Generator(device=dev).manual_seed(7 * world + M)
+    norm_w = (torch.rand(N, device=dev, generator=g) + 0.5).to(torch.bfloat16) if bpr == 1 else None
+    for it in range(5):                     # epochs advance, the buffer parity flips
+        parts = [torch.randn(ns, M, N, device=dev, generator=g) for _ in range(world)]
+        res = (torch.randn(M, N, device=dev, generator=g)).to(torch.bfloat16)
+        xs = [torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(world)]
+        xns = [torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(world)] if bpr == 1 else None
+        sums = [torch.empty(M, N, device=dev) for _ in range(world)]
+        assert vg.reduce(parts, res=[res] * world, x_out=xs, norm_w=norm_w, xn_out=xns, sum_out=sums, eps=1e-6)
+        torch.cuda.synchronize()
+        vg.check()
+        total, x, xn = _oracle(parts, res, norm_w, 1e-6)
+        for r in range(world):
+            assert torch.equal(sums[r], sums[0]), (it, r)            # bit-identical on every rank
+            assert torch.allclose(sums[r], total, rtol=1e-5, atol=1e-4), (it, r)
+            # bf16 outputs: the oracle rounds the same fp32 sum, so at most one ulp apart
+            assert torch.allclose(xs[r].float(), x.float(), rtol=1e-2, atol=1e-2), (it, r)
+            assert torch.equal(xs[r], xs[0])
+            if xn is not None:
+                assert torch.allclose(xns[r].float(), xn.float(), rtol=2e-2, atol=2e-2), (it, r)
+
+
+def test_oneshot_allreduce_32_rows_four_ranks(dev):
+    """The batched-decode message (32 x 4096 fp32 = 512 KB per rank), in place on the residual."""
+    from eventgpt_amd.parallel.comm import VirtualGroup
+    vg = VirtualGroup(4, dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    parts = [torch.randn(2, 32, 4096, device=dev, generator=g) for _ in range(4)]
+    x0 = torch.randn(32, 4096, device=dev, generator=g).to(torch.bfloat16)
+    xs = [x0.clone() for _ in range(4)]
+    assert vg.reduce(parts, res=xs, x_out=xs)            # x += sum, in place
+    torch.cuda.synchronize()
+    vg.check()
+    _, want, _ = _oracle(parts, x0, None, 1e-6)
+    for r in range(4):
+        assert torch.allclose(xs[r].float(), want.float(), rtol=1e-2, atol=1e-2)
+
+
+def test_oneshot_allreduce_graph_replays(dev):
+    """Three collectives of different sizes captured in one graph; every replay (with the
+    program's own eager work and synchronisation in between) matches the eager result."""
+    from eventgpt_amd.parallel.comm import VirtualGroup
+    W = 4
+    vg = VirtualGroup(W, dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    shapes = [(1, 4096, 1), (6, 4096, 2), (2, 4096, 1)]
+    parts = [[torch.randn(ns, M, N, device=dev, generator=g) for _ in range(W)] for (M, N, ns) in shapes]
+    outs = [[torch.zeros(M, N, device=dev) for _ in range(W)] for (M, N, ns) in shapes]
+
+    def body():
+        for p, o in zip(parts, outs):
+            assert vg.reduce(p, sum_out=o)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        body()
+    for rep in range(4):
+        for ps in parts:                 # new data between replays (eager work)
+            for p in ps:
+                p.normal_(generator=g)
+        for os_ in outs:
+            for o in os_:
+                o.fill_(-1.0)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        vg.check()
+        for ps, os_ in zip(parts, outs):
+            want = sum(p.sum(0) for p in ps)
+            for o in os_:
+                assert torch.allclose(o, want, rtol=1e-5, atol=1e-4), rep
+
+
+def test_oneshot_allreduce_wait_gives_up(dev):
+    """Only rank 0 of a 2-rank group is driven, so its peer's flag never arrives: with a tiny
+    spin limit the wait gives up, the kernel exits normally and the host sees the error."""
+    from eventgpt_amd.parallel.comm import VirtualGroup
+    vg = VirtualGroup(2, dev, spin_limit=64)
+    parts = [torch.ones(1, 1, 4096, device=dev) for _ in range(2)]
+    out = [torch.zeros(1, 4096, device=dev) for _ in range(2)]
+    assert vg.reduce(parts, sum_out=out, ranks=[0])
+    torch.cuda.synchronize()                  # the launch has drained
+    with pytest.raises(RuntimeError, match="timed out"):
+        vg.check()
+    vg.clear_errors()
+    vg.check()
+
+
+def test_message_that_does_not_fit_is_refused(dev):
+    from eventgpt_amd.parallel.comm import VirtualGroup, plan
+    assert plan(65, 4096) is None and plan(1, 4096 * 9 * 8) is None
+    vg = VirtualGroup(2, dev)
+    parts = [torch.ones(1, 65, 4096, device=dev) for _ in range(2)]
+    assert vg.reduce(parts, sum_out=[torch.zeros(65, 4096, device=dev) for _ in range(2)]) is False
+
+
+def test_sum_slabs_and_gemv_partial(dev):
+    from eventgpt_amd.ops import hip
+    g = torch.Generator(device=dev).manual_seed(3)
+    p = torch.randn(5, 7, 4096, device=dev, generator=g)
+    assert torch.allclose(hip.raw.sum_slabs(p)[0], p.sum(0), rtol=1e-6, atol=1e-5)
+    w = (torch.randn(4096, 1408, device=dev, generator=g) * 0.05).to(torch.bfloat16)
+    x = torch.randn(3, 1408, device=dev, generator=g).to(torch.bfloat16)
+    out = torch.zeros(1, 3, 4096, device=dev)
+    hip.raw.decode_gemv_partial(w, x, out)
+    want = x.float() @ w.float().t()
+    assert torch.allclose(out[0], want, rtol=2e-3, atol=2e-3)
+
+
+def test_argmax_pair_kernels(dev):
+    """Per-rank (max, index) pairs and their selection == argmax over the concatenated shards,
+    lowest index on ties."""
+    from eventgpt_amd.ops import hip
+    W, B, P, per = 4, 6, 37, 1000
+    g = torch.Generator(device=dev).manual_seed(9)
+    pairs = torch.zeros(W, B, 2, dtype=torch.int32, device=dev)
+    vals, idxs = [], []
+    for r in range(W):
+        pv = torch.randn(B, P, device=dev, generator=g)
+        pi = torch.randint(0, per, (B, P), device=dev, generator=g, dtype=torch.int32)
+        if r == 1:
+            pv[0, 5] = 50.0; pi[0, 5] = 9
+        if r == 2:
+            pv[0, 3] = 50.0; pi[0, 3] = 4       # tie with rank 1: the lower global index wins
+        hip.raw.argmax_pair_local(pv.contiguous(), pi.contiguous(), B, P, r * per, pairs[r])
+        vals.append(pv); idxs.append(pi.long() + r * per)
+    tok = torch.zeros(B, dtype=torch.int32, device=dev)
+    hip.raw.argmax_pair_select(pairs, W, B, tok)
+    v = torch.cat(vals, 1); i = torch.cat(idxs, 1)
+    best = v.max(1, keepdim=True).values
+    want = torch.where(v == best, i, torch.full_like(i, 1 << 40)).min(1).values
+    assert tok.long().tolist() == want.tolist()
+    assert int(tok[0]) == 1 * per + 9

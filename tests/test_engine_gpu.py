@@ -148,16 +148,23 @@ def test_tensor_parallel_engine_two_ranks(tmp_path):
     print("launching 2-rank TP engine worker", flush=True)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
-    got = json.load(open(out))
-    assert got["heads_local"] == 2 and got["i_local"] == 704 and got["logits_width"] == 515
-    assert got["ranks"][0] == got["ranks"][1]           # the ranks agree token for token
-    assert got["logits_equal"]
-    # same first token, and the residual stream after one more step of layers agrees with
-    # the unsharded engine up to the bf16 rounding of the partial sums (a wrong shard,
-    # position or cache row would put the cosine far below this)
-    for b, want in enumerate(got["want"]):
-        assert got["first_tok"][b] == want[0] == got["ranks"][0][b][0]
-        assert got["cos_prefill"][b] > 0.999 and got["cos_step"][b] > 0.995, got
+    allgot = json.load(open(out))
+    # 2 streams: weight-streaming GEMV path; 6 streams: split-K GEMM + fused consumers.
+    # "rccl" is the library collective (gloo through host copies here), "oneshot" the push
+    # all-reduce over IPC-mapped buffers of the two processes.
+    for key in ("b2_rccl", "b6_rccl", "b2_oneshot", "b6_oneshot"):
+        got = allgot[key]
+        assert got["heads_local"] == 2 and got["i_local"] == 704 and got["logits_width"] == 515, key
+        assert got["allreduce_kind"] == ("oneshot" if key.endswith("oneshot") else "gloo"), key
+        assert got["timeouts"] == [0, 0], (key, got["timeouts"])
+        assert got["ranks"][0] == got["ranks"][1], key          # the ranks agree token for token
+        assert got["logits_equal"], key
+        # same first token, and the residual stream after one more step of layers agrees with
+        # the unsharded engine up to the bf16 rounding of the partial sums (a wrong shard,
+        # position or cache row would put the cosine far below this)
+        for b, want in enumerate(got["want"]):
+            assert got["first_tok"][b] == want[0] == got["ranks"][0][b][0], (key, b)
+            assert got["cos_prefill"][b] > 0.999 and got["cos_step"][b] > 0.995, (key, got)
 
 
 def test_continuous_batching_matches_single_stream(model, dev):
