@@ -8,6 +8,7 @@
 //     capture into a hipGraph (no allocation, no host sync).
 // Host-side shape checks live here so a kernel is never launched on operands
 // that do not match what its indexing assumes.
+#include <algorithm>
 #include <cmath>
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
@@ -70,7 +71,7 @@ std::tuple<Tensor, Tensor> add_rmsnorm(const Tensor& x, const Tensor& res, const
   return {y, r};
 }
 
-Tensor layernorm(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, double eps) {
+Tensor layernorm(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, double eps, int64_t act) {
   check_bf16(x, "x"); check_bf16(w, "weight");
   if (b.has_value()) check_bf16(*b, "bias");
   const int64_t H = x.size(-1);
@@ -79,7 +80,7 @@ Tensor layernorm(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& 
   const int64_t rows = x.numel() / H;
   if (rows > 0)
     evgpt::launch_layernorm(bptr(x), bptr(w), bptr_opt(b), bptr_mut(y), (int)rows, (int)H,
-                            (float)eps, cur_stream());
+                            (float)eps, cur_stream(), (int)act);
   return y;
 }
 
@@ -93,6 +94,7 @@ Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bia
   TORCH_CHECK(w.size(1) == K, "linear: K mismatch (", w.size(1), " vs ", K, ")");
   TORCH_CHECK(K % 8 == 0, "linear: K must be a multiple of 8");
   const int64_t M = x.numel() / K;
+  TORCH_CHECK(M * K < (1ll << 30) && N * K < (1ll << 30), "linear: operands are addressed with 32-bit byte offsets (< 2 GiB each)");
   if (bias.has_value()) { check_bf16(*bias, "bias"); TORCH_CHECK(bias->numel() == N); }
   auto out_sizes = x.sizes().vec();
   out_sizes.back() = N;
@@ -118,6 +120,43 @@ Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bia
                             bptr_opt(res), (int)M, (int)N, (int)K, (int)K, (int)K, (int)N, (int)act,
                             nullptr, nullptr, sk > 1 ? ws.data_ptr<float>() : nullptr, sk, st);
   }
+  return y;
+}
+
+// C [M,N] = opA(a) · opW(w)^T on the MFMA GEMM with either operand K-strided:
+//   a_t = false: a is [M,K]      a_t = true: a is [Kr,M] (the contraction runs over a's rows)
+//   w_t = false: w is [N,K]      w_t = true: w is [Kr,N]
+// These are the layouts of a linear layer's backward: dX = dY · W is (a = dY, w = W, w_t) and
+// dW = dY^T · X is (a = dY, w = X, both transposed).  A K-contiguous operand must have K % 64 == 0
+// (zero-padded by the caller); K-strided operands may have any number of rows Kr <= K as long as
+// the other operand is zero for k >= Kr.
+Tensor linear_t(const Tensor& a, const Tensor& w, bool a_t, bool w_t, const c10::optional<Tensor>& bias,
+                const c10::optional<Tensor>& res, int64_t act, bool out_f32, int64_t K) {
+  check_bf16(a, "a"); check_bf16(w, "w");
+  TORCH_CHECK(a.dim() == 2 && w.dim() == 2 && (a_t || w_t), "linear_t: 2-D operands, at least one K-strided");
+  TORCH_CHECK(K % 64 == 0 && K >= 64, "linear_t: padded contraction length must be a multiple of 64");
+  const int64_t M = a_t ? a.size(1) : a.size(0), N = w_t ? w.size(1) : w.size(0);
+  int64_t ka_rows = K, kw_rows = K;
+  if (a_t) {
+    TORCH_CHECK(M % 8 == 0 && M >= 8, "linear_t: K-strided A needs M % 8 == 0");
+    ka_rows = a.size(0);
+  } else TORCH_CHECK(a.size(1) == K, "linear_t: K-contiguous A must be padded to K");
+  if (w_t) {
+    TORCH_CHECK(N % 8 == 0 && N >= 8, "linear_t: K-strided W needs N % 8 == 0");
+    kw_rows = w.size(0);
+  } else TORCH_CHECK(w.size(1) == K, "linear_t: K-contiguous W must be padded to K");
+  TORCH_CHECK(ka_rows >= 1 && kw_rows >= 1 && ka_rows <= K && kw_rows <= K && K - std::min(ka_rows, kw_rows) < 64,
+              "linear_t: K is the contraction rounded up to 64");
+  TORCH_CHECK(a.numel() < (1ll << 30) && w.numel() < (1ll << 30), "linear_t: operands < 2 GiB each");
+  TORCH_CHECK(ka_rows == K || kw_rows == K, "linear_t: one operand must cover the padded contraction (zero rows / "
+              "columns for k past the real length); the other may stop at the real length");
+  if (bias.has_value()) { check_bf16(*bias, "bias"); TORCH_CHECK(bias->numel() == N); }
+  if (res.has_value()) { check_bf16(*res, "residual"); TORCH_CHECK(res->numel() == M * N); }
+  Tensor y = at::empty({M, N}, a.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
+  if (M == 0 || N == 0) return y;
+  evgpt::launch_gemm_bf16_t(bptr(a), bptr(w), out_f32 ? nullptr : bptr_mut(y), out_f32 ? y.data_ptr<float>() : nullptr,
+                            bptr_opt(bias), bptr_opt(res), (int)M, (int)N, (int)K, (int)a.size(1), (int)w.size(1),
+                            (int)N, (int)act, a_t, w_t, (int)ka_rows, (int)kw_rows, cur_stream());
   return y;
 }
 
@@ -276,6 +315,44 @@ Tensor attention(const Tensor& q, const Tensor& k, const Tensor& v, bool causal,
                              (int)Sk, (int)Hq, (int)Hkv, (int)D, causal ? 1 : 0, (int)q_offset, 0,
                              (float)scale, cur_stream());
   return o;
+}
+
+// Training forward: attention plus the per-row log-sum-exp the backward recomputes P from.
+// q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] contiguous.  Returns (o [B,Sq,Hq,D], lse [B,Hq,Sq] fp32).
+std::tuple<Tensor, Tensor> attention_fwd_lse(const Tensor& q, const Tensor& k, const Tensor& v, bool causal,
+                                             double scale, int64_t q_offset) {
+  check_bf16(q, "q"); check_bf16(k, "k"); check_bf16(v, "v");
+  TORCH_CHECK(q.dim() == 4 && k.dim() == 4 && v.sizes() == k.sizes());
+  const int64_t B = q.size(0), Sq = q.size(1), Hq = q.size(2), D = q.size(3), Sk = k.size(1), Hkv = k.size(2);
+  TORCH_CHECK((D == 64 || D == 128) && k.size(0) == B && k.size(3) == D && Hq % Hkv == 0 && Sq >= 1 && Sk >= 1,
+              "attention_fwd_lse: shape mismatch");
+  Tensor o = at::empty_like(q);
+  Tensor lse = at::empty({B, Hq, Sq}, q.options().dtype(at::kFloat));
+  long long s[12];
+  fill_strides_bshd(q, s); fill_strides_bshd(k, s + 3); fill_strides_bshd(v, s + 6); fill_strides_bshd(o, s + 9);
+  evgpt::launch_attn_prefill(bptr(q), bptr(k), bptr(v), bptr_mut(o), s, nullptr, (int)B, (int)Sq, (int)Sk, (int)Hq,
+                             (int)Hkv, (int)D, causal ? 1 : 0, (int)q_offset, 0, (float)scale, cur_stream(), nullptr,
+                             nullptr, 0, lse.data_ptr<float>());
+  return {o, lse};
+}
+
+// (dq, dk, dv) of the attention above from the upstream gradient d_o
+std::tuple<Tensor, Tensor, Tensor> attention_bwd(const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& o,
+                                                 const Tensor& d_o, const Tensor& lse, bool causal, double scale,
+                                                 int64_t q_offset) {
+  check_bf16(q, "q"); check_bf16(k, "k"); check_bf16(v, "v"); check_bf16(o, "o"); check_bf16(d_o, "d_o");
+  check_f32(lse, "lse");
+  TORCH_CHECK(q.dim() == 4 && k.dim() == 4 && v.sizes() == k.sizes() && o.sizes() == q.sizes() &&
+              d_o.sizes() == q.sizes());
+  const int64_t B = q.size(0), Sq = q.size(1), Hq = q.size(2), D = q.size(3), Sk = k.size(1), Hkv = k.size(2);
+  TORCH_CHECK((D == 64 || D == 128) && k.size(0) == B && k.size(3) == D && Hq % Hkv == 0 && lse.numel() == B * Hq * Sq,
+              "attention_bwd: shape mismatch");
+  Tensor dq = at::empty_like(q), dk = at::empty_like(k), dv = at::empty_like(v);
+  Tensor delta = at::empty({B, Hq, Sq}, q.options().dtype(at::kFloat));
+  evgpt::launch_attn_bwd(bptr(q), bptr(k), bptr(v), bptr(o), bptr(d_o), lse.data_ptr<float>(), delta.data_ptr<float>(),
+                         bptr_mut(dq), bptr_mut(dk), bptr_mut(dv), (int)B, (int)Sq, (int)Sk, (int)Hq, (int)Hkv, (int)D,
+                         causal ? 1 : 0, (int)q_offset, (float)scale, cur_stream());
+  return {dq, dk, dv};
 }
 
 // Attention of q [B,Sq,Hq,D] against a static cache [B,Hkv,Lmax,D]; the key
@@ -748,14 +825,19 @@ Tensor vit_embed_ln(const Tensor& tok, const Tensor& cls, const Tensor& pos, con
 void verify_accept(const Tensor& pval, const Tensor& pidx, const Tensor& draft, int64_t G,
                    const Tensor& out_tokens, const Tensor& step, const Tensor& pos,
                    const Tensor& done, const Tensor& cur_token, const Tensor& result, int64_t eos,
-                   const Tensor& embed, const Tensor& x) {
+                   const Tensor& embed, const Tensor& x, const c10::optional<Tensor>& limit,
+                   const c10::optional<Tensor>& stats) {
   check_f32(pval, "pval"); check_i32(pidx, "pidx"); check_i32(draft, "draft");
   check_i32(out_tokens, "out_tokens"); check_i32(step, "step"); check_i32(pos, "pos");
   check_i32(done, "done"); check_i32(cur_token, "cur_token"); check_i32(result, "result");
   check_bf16(embed, "embed"); check_bf16(x, "x");
   TORCH_CHECK(G >= 0 && G + 1 <= 64, "verify_accept: at most 63 draft tokens");
   TORCH_CHECK(pval.dim() == 2 && pval.size(0) >= G + 1 && pidx.sizes() == pval.sizes());
-  TORCH_CHECK(draft.numel() >= G && result.numel() >= 3);
+  TORCH_CHECK(draft.numel() >= G && result.numel() >= 6, "verify_accept: result holds 6 ints");
+  const int* lim = nullptr;
+  int* stp = nullptr;
+  if (limit.has_value() && limit->defined()) { check_i32(*limit, "limit"); TORCH_CHECK(limit->numel() >= 1); lim = limit->data_ptr<int>(); }
+  if (stats.has_value() && stats->defined()) { check_i32(*stats, "stats"); TORCH_CHECK(stats->numel() >= 3); stp = stats->data_ptr<int>(); }
   const int64_t H = embed.size(1);
   TORCH_CHECK(x.numel() >= H && H % 8 == 0);
   evgpt::launch_verify_accept(pval.data_ptr<float>(), pidx.data_ptr<int>(), (int)pval.size(1),
@@ -763,7 +845,45 @@ void verify_accept(const Tensor& pval, const Tensor& pidx, const Tensor& draft, 
                               (int)out_tokens.size(-1), step.data_ptr<int>(), pos.data_ptr<int>(),
                               done.data_ptr<int>(), cur_token.data_ptr<int>(),
                               result.data_ptr<int>(), (int)eos, bptr(embed), bptr_mut(x), (int)H,
-                              (int)embed.size(0), cur_stream());
+                              (int)embed.size(0), cur_stream(), lim, stp);
+}
+
+// ---- draft head of a device-resident speculative-decoding iteration (adapter_ops.hip)
+// rows src[clamp(index[0] + offset + i, 0, n_valid - 1)], i < rows; index / n_valid live on the device
+Tensor gather_rows_dev(const Tensor& src, const Tensor& index, int64_t offset, const c10::optional<Tensor>& n_valid,
+                       int64_t rows) {
+  check_bf16(src, "src"); check_i32(index, "index");
+  TORCH_CHECK(src.dim() == 2 && src.size(0) >= 1 && src.size(1) % 8 == 0 && rows >= 1 && index.numel() >= 1);
+  const int* nv = nullptr;
+  if (n_valid.has_value() && n_valid->defined()) { check_i32(*n_valid, "n_valid"); nv = n_valid->data_ptr<int>(); }
+  Tensor out = at::empty({rows, src.size(1)}, src.options());
+  evgpt::launch_gather_rows_dev(bptr(src), index.data_ptr<int>(), (int)offset, nv, (int)src.size(0), bptr_mut(out),
+                                (int)rows, (int)src.size(1), cur_stream());
+  return out;
+}
+
+void argmax_from_partials(const Tensor& pval, const Tensor& pidx, const Tensor& token, int64_t vocab) {
+  check_f32(pval, "pval"); check_i32(pidx, "pidx"); check_i32(token, "token");
+  TORCH_CHECK(pval.dim() == 2 && pidx.sizes() == pval.sizes() && token.numel() >= pval.size(0) && vocab >= 1);
+  evgpt::launch_argmax_from_partials(pval.data_ptr<float>(), pidx.data_ptr<int>(), (int)pval.size(0),
+                                     (int)pval.size(1), token.data_ptr<int>(), (int)vocab, cur_stream());
+}
+
+// self-attention with head_dim 512 (one wave per query row); q/k/v are [B,S,H,512] views with
+// equal strides and contiguous heads (e.g. the thirds of a packed in-projection [B,S,3,H,512])
+Tensor attn_d512(const Tensor& q, const Tensor& k, const Tensor& v, bool causal, double scale) {
+  for (const Tensor* t : {&q, &k, &v}) {
+    TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kBFloat16 && t->dim() == 4 && t->size(3) == 512 &&
+                t->stride(3) == 1 && t->stride(2) == 512 && t->sizes() == q.sizes() && t->strides() == q.strides() &&
+                (reinterpret_cast<uintptr_t>(t->data_ptr()) & 15) == 0 && t->stride(1) % 8 == 0 && t->stride(0) % 8 == 0,
+                "attn_d512: [B,S,H,512] bf16 views with equal strides and contiguous heads");
+  }
+  const int64_t B = q.size(0), S = q.size(1), H = q.size(2);
+  TORCH_CHECK(S >= 1 && S <= 4096);
+  Tensor out = at::empty({B, S, H, 512}, q.options());
+  evgpt::launch_attn_d512(bptr(q), bptr(k), bptr(v), bptr_mut(out), q.stride(0), q.stride(1), (int)B, (int)S, (int)H,
+                          causal ? 1 : 0, (float)scale, cur_stream());
+  return out;
 }
 
 void sample_top_p(const Tensor& logits, const Tensor& out, double temperature, double top_p,
@@ -782,9 +902,10 @@ void sample_top_p(const Tensor& logits, const Tensor& out, double temperature, d
 TORCH_LIBRARY(evgpt, m) {
   m.def("rmsnorm(Tensor x, Tensor w, float eps) -> Tensor", &rmsnorm);
   m.def("add_rmsnorm(Tensor x, Tensor res, Tensor w, float eps) -> (Tensor, Tensor)", &add_rmsnorm);
-  m.def("layernorm(Tensor x, Tensor w, Tensor? b, float eps) -> Tensor", &layernorm);
+  m.def("layernorm(Tensor x, Tensor w, Tensor? b, float eps, int act=0) -> Tensor", &layernorm);
   m.def("linear(Tensor x, Tensor w, Tensor? bias, Tensor? res, int act, bool out_f32) -> Tensor", &linear);
   m.def("linear_partial(Tensor x, Tensor w) -> Tensor", &linear_partial);
+  m.def("linear_t(Tensor a, Tensor w, bool a_t, bool w_t, Tensor? bias, Tensor? res, int act, bool out_f32, int K) -> Tensor", &linear_t);
   m.def("gemv_max_batch() -> int", []() -> int64_t { return evgpt::gemv_max_batch(); });
   m.def("reduce_residual_norm(Tensor partial, Tensor? res, Tensor? norm_w, float eps, Tensor(a!)? out) -> (Tensor, Tensor)", &reduce_residual_norm);
   m.def("reduce_swiglu(Tensor partial) -> Tensor", &reduce_swiglu);
@@ -792,6 +913,8 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("swiglu(Tensor gate_up) -> Tensor", &swiglu);
   m.def("rope(Tensor x, Tensor positions, Tensor cos, Tensor sin) -> Tensor", &rope);
   m.def("attention(Tensor q, Tensor k, Tensor v, bool causal, float scale, int q_offset) -> Tensor", &attention);
+  m.def("attention_fwd_lse(Tensor q, Tensor k, Tensor v, bool causal, float scale, int q_offset) -> (Tensor, Tensor)", &attention_fwd_lse);
+  m.def("attention_bwd(Tensor q, Tensor k, Tensor v, Tensor o, Tensor d_o, Tensor lse, bool causal, float scale, int q_offset) -> (Tensor, Tensor, Tensor)", &attention_bwd);
   m.def("attention_cache(Tensor q, Tensor k_cache, Tensor v_cache, Tensor(a!) out, Tensor kv_len, float scale) -> ()", &attention_cache);
   m.def("st_pool(Tensor f, int n_temporal) -> Tensor", &st_pool);
   m.def("argmax_rows(Tensor x) -> Tensor", &argmax_rows);
@@ -822,7 +945,10 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("decode_gemv_partial(Tensor w, Tensor xin, Tensor(a!) out_f32) -> ()", &decode_gemv_partial);
   m.def("patchify(Tensor px, int P) -> Tensor", &patchify);
   m.def("vit_embed_ln(Tensor tok, Tensor cls, Tensor pos, Tensor w, Tensor b, float eps) -> Tensor", &vit_embed_ln);
-  m.def("verify_accept(Tensor pval, Tensor pidx, Tensor draft, int G, Tensor(a!) out_tokens, Tensor(b!) step, Tensor(c!) pos, Tensor(d!) done, Tensor(e!) cur_token, Tensor(f!) result, int eos, Tensor embed, Tensor(g!) x) -> ()", &verify_accept);
+  m.def("verify_accept(Tensor pval, Tensor pidx, Tensor draft, int G, Tensor(a!) out_tokens, Tensor(b!) step, Tensor(c!) pos, Tensor(d!) done, Tensor(e!) cur_token, Tensor(f!) result, int eos, Tensor embed, Tensor(g!) x, Tensor? limit=None, Tensor(h!)? stats=None) -> ()", &verify_accept);
+  m.def("gather_rows_dev(Tensor src, Tensor index, int offset, Tensor? n_valid, int rows) -> Tensor", &gather_rows_dev);
+  m.def("argmax_from_partials(Tensor pval, Tensor pidx, Tensor(a!) token, int vocab) -> ()", &argmax_from_partials);
+  m.def("attn_d512(Tensor q, Tensor k, Tensor v, bool causal, float scale) -> Tensor", &attn_d512);
   m.def("sample_top_p(Tensor logits, Tensor(a!) out, float temperature, float top_p, int seed, Tensor step) -> ()", &sample_top_p);
   m.def("prefill_rope_kv(Tensor qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos0, int Hq, int Hkv, int D) -> ()", &prefill_rope_kv);
 }

@@ -54,6 +54,9 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
                       const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
                       float* amax_val, int* amax_idx, float* splitk_ws, int splitk,
                       hipStream_t st);
+void launch_gemm_bf16_t(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,
+                        const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
+                        bool a_t, bool w_t, int ka_rows, int kw_rows, hipStream_t st);
 int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M, int N, int K,
                         int lda, int ldw, hipStream_t st);
 int gemm_splitk(int M, int N, int K);   // planned split count (1 = none); ws = splitk*M*N floats
@@ -71,11 +74,20 @@ void launch_clip_preproc(const unsigned char* img, bf16_t* out, const int* hstar
                          int resize_h, int resize_w, int top, int left, int ksh, int ksv,
                          const float* mean, const float* stdv, hipStream_t st);
 
+// ---- adapter_ops.hip (device-resident speculative-decoding draft head)
+void launch_gather_rows_dev(const bf16_t* src, const int* index, int offset, const int* n_valid_dev,
+                            int n_rows_src, bf16_t* out, int rows, int H, hipStream_t st);
+void launch_argmax_from_partials(const float* pval, const int* pidx, int rows, int n_part, int* token,
+                                 int vocab, hipStream_t st);
+void launch_attn_d512(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, long long sb,
+                      long long ss, int B, int S, int H, int causal, float scale, hipStream_t st);
+
 // ---- sd.hip
 void launch_verify_accept(const float* pval, const int* pidx, int n_part, const int* draft, int G,
                           int* out_tokens, int max_out, int* step, int* pos, int* done,
                           int* cur_token, int* result, int eos, const bf16_t* embed, bf16_t* x,
-                          int H, int vocab, hipStream_t st);
+                          int H, int vocab, hipStream_t st, const int* limit = nullptr,
+                          int* stats = nullptr);
 void launch_sample_top_p(const float* logits, int* out, int B, int V, float temperature,
                          float top_p, unsigned long long seed, const int* step,
                          hipStream_t st);
@@ -84,7 +96,7 @@ void launch_sample_top_p(const float* logits, int* out, int B, int V, float temp
 void launch_rmsnorm(const bf16_t* x, const bf16_t* res, const bf16_t* w, bf16_t* y,
                     bf16_t* res_out, int rows, int H, float eps, hipStream_t st);
 void launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows,
-                      int H, float eps, hipStream_t st);
+                      int H, float eps, hipStream_t st, int act = 0);
 void launch_rope_kv_prefill(const bf16_t* qkv, bf16_t* q_out, bf16_t* k_cache, bf16_t* v_cache,
                             const float* cos_tab, const float* sin_tab, const int* pos0, int B,
                             int S, int Hq, int Hkv, int D, int l_max, hipStream_t st);
@@ -168,6 +180,13 @@ void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16
                          const long long* strides, const int* kv_len, int B, int Sq, int Sk,
                          int Hq, int Hkv, int D, int causal, int q_offset, int q_offset_from_len,
                          float scale, hipStream_t st, float* part_o = nullptr,
-                         float* part_ml = nullptr, int nsplit = 0);
+                         float* part_ml = nullptr, int nsplit = 0, float* lse = nullptr);
+
+// ---- attn_bwd.hip: flash-attention backward (recomputes P from the forward's LSE)
+// q/do/dq [B,Sq,Hq,D], k/v/dk/dv [B,Sk,Hkv,D], o [B,Sq,Hq,D], all contiguous bf16;
+// lse [B,Hq,Sq] from the forward; delta [B,Hq,Sq] scratch.
+void launch_attn_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* o, const bf16_t* d_o,
+                     const float* lse, float* delta, bf16_t* dq, bf16_t* dk, bf16_t* dv, int B, int Sq,
+                     int Sk, int Hq, int Hkv, int D, int causal, int q_offset, float scale, hipStream_t st);
 
 }  // namespace evgpt

@@ -19,6 +19,7 @@
 // LDS images are XOR-swizzled at 16-byte-chunk granularity so both the row
 // reads (ds_read_b128) and the transposed reads spread over the banks.
 #include "common.h"
+#include "attn_common.h"
 #include "../evgpt_kernels.h"
 
 namespace evgpt {
@@ -38,28 +39,9 @@ struct AttnParams {
   float* part_o;                // [B][Hq][nsplit][Sq][D] unnormalised fp32
   float* part_ml;               // [B][Hq][nsplit][Sq][2] (running max in log2 units, sum)
   int nsplit;
+  float* lse;                   // optional [B][Hq][Sq]: log2 of the row's softmax denominator in the
+                                // scaled-log2 domain (max + log2(sum)); the backward recomputes P from it
 };
-
-constexpr int TK = 64;  // keys per tile
-
-template <int D> __device__ __forceinline__ int swz(int row);
-// Two access patterns must both be conflict-free (LDS serves 256 B per cycle):
-//   * ds_read_b128 of one chunk column over 16 consecutive rows (K fragments):
-//     the 16 rows must land on 16 distinct 16-byte slots of the 256-byte bank row;
-//   * ds_read_tr16_b64 (V^T fragments): 32 lanes per cycle read 32 contiguous
-//     bytes (one aligned chunk pair) of each of 8 consecutive rows: the 8 rows must
-//     land on 8 distinct 32-byte slots.
-// D = 128 (256-byte rows): chunk bits [3:1] ^= row & 7, bit 0 ^= row bit 3.
-// D = 64 (128-byte rows, two per bank row; row bit 0 picks the half): chunk bits
-// [2:1] ^= (row >> 1) & 3, bit 0 ^= row bit 3.
-template <> __device__ __forceinline__ int swz<128>(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
-template <> __device__ __forceinline__ int swz<64>(int row) { return (((row >> 1) & 3) << 1) | ((row >> 3) & 1); }
-
-// byte offset of 16-byte chunk `ch` of row `row` inside a [TK][D] bf16 tile
-template <int D>
-__device__ __forceinline__ int tile_off(int row, int ch) {
-  return row * (D * 2) + ((ch ^ swz<D>(row)) << 4);
-}
 
 template <int D, bool CAUSAL, bool SPLIT = false>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
@@ -242,6 +224,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     return;
   }
   const float inv = l > 0.f ? 1.f / l : 0.f;
+  if (p.lse && g == 0 && qi < p.Sq)
+    p.lse[(static_cast<long long>(b) * p.Hq + h) * p.Sq + qi] = l > 0.f ? m + log2f(l) : INFINITY;
   if (qi < p.Sq) {
     bf16_t* op = p.o + b * p.o_sb + static_cast<long long>(qi) * p.o_ss + h * p.o_sh;
 #pragma unroll
@@ -291,9 +275,9 @@ void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16
                          const long long* strides /*12: q,k,v,o x (b,s,h)*/, const int* kv_len,
                          int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, int q_offset,
                          int q_offset_from_len, float scale, hipStream_t st, float* part_o,
-                         float* part_ml, int nsplit) {
+                         float* part_ml, int nsplit, float* lse) {
   AttnParams p;
-  p.part_o = part_o; p.part_ml = part_ml; p.nsplit = nsplit;
+  p.part_o = part_o; p.part_ml = part_ml; p.nsplit = nsplit; p.lse = lse;
   p.q = q; p.k = k; p.v = v; p.o = o;
   p.q_sb = strides[0]; p.q_ss = strides[1]; p.q_sh = strides[2];
   p.k_sb = strides[3]; p.k_ss = strides[4]; p.k_sh = strides[5];

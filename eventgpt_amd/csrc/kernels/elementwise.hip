@@ -59,10 +59,11 @@ void launch_rmsnorm(const bf16_t* x, const bf16_t* res, const bf16_t* w, bf16_t*
 }
 
 // --------------------------------------------------------------- LayerNorm
+// `act` (ACT_*) is applied to the normalised output (the adapters' LN -> GELU).
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x,
                                                         const bf16_t* __restrict__ w,
                                                         const bf16_t* __restrict__ b,
-                                                        bf16_t* __restrict__ y, int H, float eps) {
+                                                        bf16_t* __restrict__ y, int H, float eps, int act) {
   __shared__ float red[16];
   const size_t base = static_cast<size_t>(blockIdx.x) * H;
   const int nchunk = H >> 3;
@@ -90,8 +91,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     u32x4_t o;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      o[i] = pack_bf16x2((bf16lo(v[i]) - mean) * rstd * bf16lo(g[i]) + bf16lo(bb[i]),
-                         (bf16hi(v[i]) - mean) * rstd * bf16hi(g[i]) + bf16hi(bb[i]));
+      o[i] = pack_bf16x2(apply_act((bf16lo(v[i]) - mean) * rstd * bf16lo(g[i]) + bf16lo(bb[i]), act),
+                         apply_act((bf16hi(v[i]) - mean) * rstd * bf16hi(g[i]) + bf16hi(bb[i]), act));
     *reinterpret_cast<u32x4_t*>(y + base + c * 8) = o;
   }
 }
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void layernorm_wave_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ w,
                                                              const bf16_t* __restrict__ b,
                                                              bf16_t* __restrict__ y, int rows, int H,
-                                                             float eps) {
+                                                             float eps, int act) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= rows) return;
   const size_t base = static_cast<size_t>(r) * H;
@@ -146,24 +147,24 @@ __global__ __launch_bounds__(256) void layernorm_wave_kernel(const bf16_t* __res
       u32x4_t o;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        o[j] = pack_bf16x2((bf16lo(v[i][j]) - mean) * rstd * bf16lo(g[i][j]) + bf16lo(bb[i][j]),
-                           (bf16hi(v[i][j]) - mean) * rstd * bf16hi(g[i][j]) + bf16hi(bb[i][j]));
+        o[j] = pack_bf16x2(apply_act((bf16lo(v[i][j]) - mean) * rstd * bf16lo(g[i][j]) + bf16lo(bb[i][j]), act),
+                           apply_act((bf16hi(v[i][j]) - mean) * rstd * bf16hi(g[i][j]) + bf16hi(bb[i][j]), act));
       *reinterpret_cast<u32x4_t*>(y + base + c * 8) = o;
     }
   }
 }
 
 void launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows,
-                      int H, float eps, hipStream_t st) {
+                      int H, float eps, hipStream_t st, int act) {
   const int nchunk = H >> 3;
   if (rows >= 64 && nchunk <= 128) {
     hipLaunchKernelGGL(layernorm_wave_kernel<2>, dim3((rows + 3) / 4), dim3(256), 0, st, x, w, b, y,
-                       rows, H, eps);
+                       rows, H, eps, act);
   } else if (rows >= 64 && nchunk <= 256) {
     hipLaunchKernelGGL(layernorm_wave_kernel<4>, dim3((rows + 3) / 4), dim3(256), 0, st, x, w, b, y,
-                       rows, H, eps);
+                       rows, H, eps, act);
   } else {
-    hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, st, x, w, b, y, H, eps);
+    hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, st, x, w, b, y, H, eps, act);
   }
 }
 

@@ -8,8 +8,10 @@
 //   * block tile BM x BN x 64, 4 waves; each wave owns a (BM/WGM) x (BN/WGN)
 //     sub-tile built from 16x16x32 bf16 MFMAs;
 //   * operands are staged HBM -> LDS with direct-to-LDS 16-byte loads
-//     (global_load_lds_dwordx4), double buffered: the loads of K-tile t+1 are
-//     issued before the MFMAs of tile t, one barrier per K-tile;
+//     (buffer_load_dwordx4 ... lds through a wave-uniform descriptor that is rebased
+//     per K-tile, so the loop carries no per-lane address arithmetic), multi-buffered:
+//     the loads of K-tiles t+1.. are issued before the MFMAs of tile t, one barrier
+//     per K-tile;
 //   * LDS rows are 128 B, so rows two apart share banks; a 16-byte-chunk XOR
 //     swizzle  chunk' = chunk ^ ((row >> 1) & 7)  makes every ds_read_b128
 //     16-lane group hit 16 distinct slots.  Direct-to-LDS writes are
@@ -23,6 +25,17 @@
 //     tiles that share weight panels.
 // Any M, N; K must be a multiple of 64 (callers pad).  Rows past M / N are
 // clamped on load and masked on store.
+//
+// Operand layouts for training (template flags AT / BT): an operand may instead be given
+// K-STRIDED, i.e. stored [K][M] (A^T) or [K][N] (W^T) -- the layouts of the backward
+// products  dX = dY · W  (W [N][K] is the K-strided "weight" of a contraction over N) and
+// dW = dY^T · X  (both operands strided in the token dimension).  Such a tile is staged
+// as [64 k-rows][BM or BN columns] with the same direct-to-LDS loads and its MFMA
+// fragments are gathered with the transposing read ds_read_b64_tr_b16: two reads give a
+// lane its column's 8 consecutive k, the same fragment a ds_read_b128 gives for a
+// K-contiguous operand, so any mix of layouts feeds the same MFMA.  The image is
+// XOR-swizzled (on the source address and on the read) so that the 8 k-rows a half-wave
+// gathers at once fall on 8 distinct 32-byte bank slots.
 #include "common.h"
 #include "../evgpt_kernels.h"
 
@@ -51,6 +64,9 @@ struct GemmParams {
   int splitk, k_per_split;
   float* partial;
   int raw_partial;     // store the fp32 slab even when splitk == 1 (a fused consumer sums it)
+  // K-strided operands only: k-rows that exist in memory.  A padded contraction (K rounded up
+  // to 64) re-reads the last real row for k >= k_rows; the other operand holds zeros there.
+  int ka_rows, kw_rows;
 };
 
 // wait until at most `n` of this wave's direct-to-LDS loads are still in flight
@@ -73,8 +89,34 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else static_assert(N == 0, "add the literal");
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES>
+// swizzle of the 16-byte chunk index of k-row `row` in a K-strided tile whose rows hold BX
+// columns: a half-wave's transposed read touches k-rows {8g+q} or {8g+4+q} (g in {0,1} or
+// {2,3}, q = 0..3), which must land on 8 distinct 32-byte slots of the 256-byte bank row
+template <int BX> __device__ __forceinline__ int swz_t(int row) {
+  if constexpr (BX == 128) return ((row & 3) | (((row >> 3) & 1) << 2)) << 1;          // 256-B rows
+  else return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;                         // 128-B rows, 2 per bank row
+}
+
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+// fragment of a K-strided tile: columns cb + (lane & 15), k = 32*ks + 8*(lane >> 4) + 0..7
+template <int BX>
+__device__ __forceinline__ bf16x8_t frag_t(const unsigned char* tile, int cb, int ks, int lane) {
+  const int fr = lane & 15, g = lane >> 4, q = fr >> 2, pp = fr & 3;
+  const int row1 = ks * 32 + 8 * g + q, row2 = row1 + 4;
+  const int chunk = (cb >> 3) + (pp >> 1);
+  const unsigned char* a1 = tile + row1 * (BX * 2) + ((chunk ^ swz_t<BX>(row1)) << 4) + 8 * (pp & 1);
+  const unsigned char* a2 = tile + row2 * (BX * 2) + ((chunk ^ swz_t<BX>(row2)) << 4) + 8 * (pp & 1);
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)a1);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)a2);
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool AT = false, bool BT = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+  static_assert(!AT || BM == 64 || BM == 128, "K-strided A needs a 64- or 128-row tile");
+  static_assert(!BT || BN == 64 || BN == 128, "K-strided W needs a 64- or 128-column tile");
   constexpr int WM = BM / WGM, WN = BN / WGN;  // per-wave tile
   constexpr int TM = WM / 16, TN = WN / 16;    // 16x16 tiles per wave
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -93,28 +135,69 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   const int m0 = tm * BM, n0 = tn * BN;
   const int wr = wid / WGN, wc = wid % WGN;
 
-  // ---- staging: one wave-instruction = 8 rows x 128 B, lane -> (row, chunk')
+  // ---- staging: one wave-instruction = 1 KiB of the LDS image (8 rows x 128 B of a
+  // K-contiguous tile, or 1024 / (2 BX) k-rows of a K-strided one).  The loads are
+  // buffer_load ... lds: the per-lane source offset (row, swizzled chunk) is computed ONCE,
+  // and each K-tile only rebases the wave-uniform buffer descriptor (scalar ALU) -- the K
+  // loop issues no vector address arithmetic for staging (global_load_lds with per-lane
+  // 64-bit addresses cost ~20 VALU instructions per load, more than the loop's MFMAs).
+  // The descriptor's range check returns zeros for rows past M / N / the contraction
+  // length, so edge tiles need no clamping.
   const int srow = lane >> 3, schunk = lane & 7;
+  const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+  int voff_a[BM / 32], voff_w[BN / 32];
+#pragma unroll
+  for (int i = 0; i < BM / 32; ++i) {
+    const int rg = wid_u * (BM / 32) + i;
+    if constexpr (AT) {
+      constexpr int CPR = BM / 8;
+      const int lin = rg * 64 + lane;                 // 16-byte chunk index in the image
+      const int row = lin / CPR, cl = (lin % CPR) ^ swz_t<BM>(row);
+      voff_a[i] = (row * p.lda + m0 + cl * 8) * 2;
+    } else {
+      const int row = rg * 8 + srow;
+      const int c = schunk ^ ((row >> 1) & 7);
+      voff_a[i] = ((m0 + row) * p.lda + c * 8) * 2;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BN / 32; ++i) {
+    const int rg = wid_u * (BN / 32) + i;
+    if constexpr (BT) {
+      constexpr int CPR = BN / 8;
+      const int lin = rg * 64 + lane;
+      const int row = lin / CPR, cl = (lin % CPR) ^ swz_t<BN>(row);
+      voff_w[i] = (row * p.ldw + n0 + cl * 8) * 2;
+    } else {
+      const int row = rg * 8 + srow;
+      const int c = schunk ^ ((row >> 1) & 7);
+      voff_w[i] = ((n0 + row) * p.ldw + c * 8) * 2;
+    }
+  }
+  // bytes of each operand that exist in memory (everything past them reads as zero)
+  const long long bytes_a = 2ll * (AT ? p.ka_rows : p.M) * p.lda;
+  const long long bytes_w = 2ll * (BT ? p.kw_rows : p.N) * p.ldw;
   auto stage = [&](int buf, int kt) {
     unsigned char* base = smem + buf * STAGE;
     const int k0 = k_begin + kt * BK;
+    const long long adv_a = AT ? 2ll * k0 * p.lda : 2ll * k0;
+    const long long adv_w = BT ? 2ll * k0 * p.ldw : 2ll * k0;
+    const long long left_a = bytes_a - adv_a, left_w = bytes_w - adv_w;
+    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.A)) + adv_a, 0,
+        static_cast<int>(left_a > 0 ? left_a : 0), 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.W)) + adv_w, 0,
+        static_cast<int>(left_w > 0 ? left_w : 0), 0x00020000);
 #pragma unroll
     for (int i = 0; i < BM / 32; ++i) {  // BM/8 row-groups over 4 waves
-      const int rg = wid * (BM / 32) + i;
-      const int row = rg * 8 + srow;
-      const int c = schunk ^ ((row >> 1) & 7);
-      int gr = m0 + row; gr = gr < p.M ? gr : p.M - 1;
-      const bf16_t* src = p.A + static_cast<size_t>(gr) * p.lda + k0 + c * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + rg * 1024), 16, 0, 0);
+      const int rg = wid_u * (BM / 32) + i;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(base + rg * 1024), 16, voff_a[i], 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) {
-      const int rg = wid * (BN / 32) + i;
-      const int row = rg * 8 + srow;
-      const int c = schunk ^ ((row >> 1) & 7);
-      int gr = n0 + row; gr = gr < p.N ? gr : p.N - 1;
-      const bf16_t* src = p.W + static_cast<size_t>(gr) * p.ldw + k0 + c * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + A_BYTES + rg * 1024), 16, 0, 0);
+      const int rg = wid_u * (BN / 32) + i;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(base + A_BYTES + rg * 1024), 16, voff_w[i], 0, 0, 0);
     }
   };
 
@@ -158,11 +241,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
       const int off = ((ks * 4 + fq) ^ fsw) * 16;
       bf16x8_t af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const bf16x8_t*>(a_base + i * 16 * 128 + off);
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (AT) af[i] = frag_t<BM>(smem + cur * STAGE, wr * WM + i * 16, ks, lane);
+        else af[i] = *reinterpret_cast<const bf16x8_t*>(a_base + i * 16 * 128 + off);
+      }
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const bf16x8_t*>(b_base + j * 16 * 128 + off);
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (BT) bf[j] = frag_t<BN>(smem + cur * STAGE + A_BYTES, wc * WN + j * 16, ks, lane);
+        else bf[j] = *reinterpret_cast<const bf16x8_t*>(b_base + j * 16 * 128 + off);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -291,17 +378,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES>
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool AT = false, bool BT = false>
 static void launch_cfg(const GemmParams& p, hipStream_t st) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk;
   constexpr size_t smem = static_cast<size_t>(STAGES) * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES, AT, BT>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES>), dim3(tiles), dim3(256), smem,
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES, AT, BT>), dim3(tiles), dim3(256), smem,
                      st, p);
 }
 
@@ -368,7 +455,7 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
                       float* amax_val, int* amax_idx, float* splitk_ws, int splitk,
                       hipStream_t st) {
   GemmParams p{A, W, C, bias, res, Cf, M, N, K, lda, ldw, ldc, act, amax_val, amax_idx, 1, K,
-               nullptr, 0};
+               nullptr, 0, K, K};
   if (splitk > 1 && splitk_ws && !amax_val) {
     const int ksteps = K / 64;
     p.splitk = splitk;
@@ -391,12 +478,37 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
   }
 }
 
+// C[M,N] = opA · opW^T with K-strided operands: a_t -> A is stored [K][M] (lda = its row
+// stride), w_t -> W is stored [K][N].  Used by the backward products of a linear layer.
+// M (if a_t) and N (if w_t) must be multiples of 8 and >= 8; K a multiple of 64; ka_rows /
+// kw_rows <= K are the k-rows the K-strided operands really have (see GemmParams).
+template <bool AT, bool BT>
+static void launch_t(const GemmParams& p, hipStream_t st) {
+  auto tiles = [&](int bm, int bn) {
+    return static_cast<long long>((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+  };
+  if (tiles(128, 128) >= 384) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
+  else if (tiles(64, 128) >= 300) launch_cfg<64, 128, 2, 2, 3, AT, BT>(p, st);
+  else launch_cfg<64, 64, 2, 2, 4, AT, BT>(p, st);
+}
+
+void launch_gemm_bf16_t(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,
+                        const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
+                        bool a_t, bool w_t, int ka_rows, int kw_rows, hipStream_t st) {
+  GemmParams p{A, W, C, bias, res, Cf, M, N, K, lda, ldw, ldc, act, nullptr, nullptr, 1, K, nullptr, 0,
+               ka_rows, kw_rows};
+  if (a_t && w_t) launch_t<true, true>(p, st);
+  else if (a_t) launch_t<true, false>(p, st);
+  else if (w_t) launch_t<false, true>(p, st);
+  else launch_t<false, false>(p, st);
+}
+
 // Projection that stops at the fp32 split-K slabs partial[nslab][M][N]; returns
 // nslab (>= 1).  `partial` holds gemm_splitk(M, N, K) * M * N floats.
 int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M, int N, int K,
                         int lda, int ldw, hipStream_t st) {
   GemmParams p{A, W, nullptr, nullptr, nullptr, nullptr, M, N, K, lda, ldw, N, ACT_NONE, nullptr,
-               nullptr, 1, K, partial, 1};
+               nullptr, 1, K, partial, 1, K, K};
   const int splitk = gemm_splitk(M, N, K);
   if (splitk > 1) {
     const int ksteps = K / 64;

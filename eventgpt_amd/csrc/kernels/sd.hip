@@ -22,9 +22,18 @@ __global__ __launch_bounds__(256) void verify_accept_kernel(
     const int* __restrict__ draft, int G, int* __restrict__ out_tokens, int max_out,
     int* __restrict__ step, int* __restrict__ pos, int* __restrict__ done,
     int* __restrict__ cur_token, int* __restrict__ result, int eos,
-    const bf16_t* __restrict__ embed, bf16_t* __restrict__ x, int H, int vocab) {
+    const bf16_t* __restrict__ embed, bf16_t* __restrict__ x, int H, int vocab,
+    const int* __restrict__ limit, int* __restrict__ stats) {
   __shared__ int amax[VA_MAX_ROWS];
   __shared__ int next_s;
+  // A host that replays whole draft/verify iterations without reading anything back passes
+  // `limit`: once the sequence is done, or limit[0] tokens are out, a replay changes nothing
+  // (its forward pass only wrote cache rows past the final position).  result[3..5] mirror
+  // step / done / pos so one small read tells the host where the sequence stands.
+  if (limit && (done[0] || step[0] >= limit[0])) {       // block-uniform
+    if (threadIdx.x == 0) { result[0] = 0; result[2] = 0; result[3] = step[0]; result[4] = done[0]; result[5] = pos[0]; }
+    return;
+  }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int rows = G + 1;
   // one wave per row: reduce that row's partials (lowest index on ties)
@@ -66,6 +75,8 @@ __global__ __launch_bounds__(256) void verify_accept_kernel(
     cur_token[0] = next;
     if (hit_eos) done[0] = 1;
     result[0] = n_acc; result[1] = next; result[2] = emitted;
+    result[3] = st; result[4] = hit_eos ? 1 : done[0]; result[5] = pos[0];
+    if (stats) { stats[0] += G; stats[1] += n_acc; stats[2] += 1; }
     next_s = next;
   }
   __syncthreads();
@@ -78,9 +89,10 @@ __global__ __launch_bounds__(256) void verify_accept_kernel(
 void launch_verify_accept(const float* pval, const int* pidx, int n_part, const int* draft, int G,
                           int* out_tokens, int max_out, int* step, int* pos, int* done,
                           int* cur_token, int* result, int eos, const bf16_t* embed, bf16_t* x,
-                          int H, int vocab, hipStream_t st) {
+                          int H, int vocab, hipStream_t st, const int* limit, int* stats) {
   hipLaunchKernelGGL(verify_accept_kernel, dim3(1), dim3(256), 0, st, pval, pidx, n_part, draft, G,
-                     out_tokens, max_out, step, pos, done, cur_token, result, eos, embed, x, H, vocab);
+                     out_tokens, max_out, step, pos, done, cur_token, result, eos, embed, x, H, vocab,
+                     limit, stats);
 }
 
 // ---------------------------------------------------------------- sampler

@@ -1,12 +1,23 @@
 """Differentiable GPU path: the ops a training step differentiates through, in the
-tensors' own dtype on PyTorch-ROCm's library kernels.
+tensors' own dtype.
 
-The hand-written kernels in ``ops.hip`` are inference kernels (no backward) and
 ``ops.reference`` is the fp32 oracle (it upcasts every operand, which for a 7B decoder
 means re-materialising each weight matrix in fp32 on every call).  A call on GPU tensors
-that needs autograd comes here instead: bf16 GEMMs with fp32 accumulation through
-``F.linear`` (hipBLASLt), ``F.scaled_dot_product_attention``, fp32 statistics only on the
-activations of the norms.  Semantics match the oracle; rounding is that of bf16 training.
+that needs autograd comes here instead.  On bf16 tensors every op is an
+``autograd.Function`` over the in-tree gfx950 kernels:
+
+* ``linear``: forward, dgrad ``dX = dY W`` and wgrad ``dW = dY^T X`` all run the MFMA GEMM
+  of ``csrc/kernels/gemm.hip``; the backward products read their K-strided operands
+  (``W`` for dgrad, both ``dY`` and ``X`` for wgrad) through transposing LDS reads, so no
+  transposed copy of a weight or an activation is ever written;
+* ``attention``: the fused forward also returns the per-row log-sum-exp, and the backward
+  (``csrc/kernels/attn_bwd.hip``) recomputes the probabilities from it;
+* RMSNorm, RoPE and SwiGLU: the inference kernel in forward and one backward kernel each.
+
+Other dtypes (fp32 parameters under autocast, shapes the kernels do not take) fall back to
+PyTorch-ROCm library ops with the same semantics; rounding is that of bf16 training.
+The reference trains through HF / PEFT modules on cuBLAS and flash-attn
+(pipeline/adapter_train/train_lora_adapter.py:458-524).
 
 RMSNorm, RoPE and SwiGLU on bf16 tensors are ``autograd.Function``s over the HIP kernels:
 the inference kernel in forward and one backward kernel each (``csrc/kernels/train_bwd.hip``;
@@ -102,8 +113,80 @@ def layernorm(x, weight, bias, eps: float = 1e-5):
     return F.layer_norm(x, (x.shape[-1],), weight.to(x.dtype), None if bias is None else bias.to(x.dtype), eps)
 
 
+def _round64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+def _pad_cols(t: torch.Tensor, k: int) -> torch.Tensor:
+    return t if t.shape[1] == k else F.pad(t, (0, k - t.shape[1]))
+
+
+def _pad_rows(t: torch.Tensor, k: int) -> torch.Tensor:
+    return t if t.shape[0] == k else F.pad(t, (0, 0, 0, k - t.shape[0]))
+
+
+def linear_dgrad(gy: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """``dX [M,K] = dY [M,N] @ W [N,K]``: the contraction runs over W's ROWS, so W is the
+    K-strided operand of the GEMM (read through transposing LDS loads, never copied)."""
+    n = gy.shape[1]
+    return _raw().linear_t(_pad_cols(gy, _round64(n)), weight, False, True, None, None, 0, False, _round64(n))
+
+
+def linear_wgrad(gy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """``dW [N,K] = dY^T [N,M] @ X [M,K]``: both operands are strided in the token dimension."""
+    m = gy.shape[0]
+    mp = _round64(m)
+    if mp != m:      # zero rows on the smaller operand; the other one's tail rows are re-read and multiplied by 0
+        if gy.shape[1] <= x.shape[1]:
+            gy = _pad_rows(gy, mp)
+        else:
+            x = _pad_rows(x, mp)
+    return _raw().linear_t(gy, x, True, True, None, None, 0, False, mp)
+
+
+class _Linear(torch.autograd.Function):
+    """``y = x @ W^T + b`` on the in-tree MFMA GEMM, forward and both backward products."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        k = x.shape[-1]
+        x2 = x.reshape(-1, k)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        from . import hip
+        y = hip.linear(x2, weight, bias)
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight = ctx.saved_tensors
+        n = weight.shape[0]
+        g2 = gy.reshape(-1, n)
+        g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_dgrad(g2, weight.contiguous()).view(*gy.shape[:-1], weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            dw = linear_wgrad(g2, x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g2.float().sum(0).to(gy.dtype)
+        return dx, dw, db
+
+
+def _linear_fused_ok(x, weight, bias) -> bool:
+    if not _fused(x, weight, bias) or weight.dim() != 2 or x.numel() == 0:
+        return False
+    n, k = weight.shape
+    # K-strided operands move in 16-byte chunks along their contiguous dimension
+    return n % 8 == 0 and k % 8 == 0 and n >= 8 and k >= 8 and x.shape[-1] == k
+
+
 def linear(x, weight, bias=None, act: Optional[str] = None, residual=None):
-    y = F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
+    if _linear_fused_ok(x, weight, bias):
+        y = _Linear.apply(x, weight, bias)
+    else:
+        y = F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
     y = _ACTS[act](y)
     return y if residual is None else y + residual
 
@@ -126,11 +209,33 @@ def apply_rope(x, positions, cos, sin):
     return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], dim=-1)
 
 
+class _Attention(torch.autograd.Function):
+    """Fused attention forward (+ log-sum-exp) and flash backward on the in-tree kernels."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, causal, scale, q_offset):
+        qc, kc, vc = q.contiguous(), k.contiguous(), v.contiguous()
+        o, lse = _raw().attention_fwd_lse(qc, kc, vc, bool(causal), float(scale), int(q_offset))
+        ctx.save_for_backward(qc, kc, vc, o, lse)
+        ctx.args = (bool(causal), float(scale), int(q_offset))
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, o, lse = ctx.saved_tensors
+        causal, scale, q_offset = ctx.args
+        dq, dk, dv = _raw().attention_bwd(q, k, v, o, g.contiguous(), lse, causal, scale, q_offset)
+        return dq, dk, dv, None, None, None
+
+
 def attention(q, k, v, causal: bool, scale: Optional[float] = None, q_offset: int = 0, key_padding_mask=None):
     """``[B,S,H,D]`` in and out; grouped KV heads are expanded; masks as in the oracle."""
     b, sq, h, d = q.shape
     sk, hk = k.shape[1], k.shape[2]
     scale = scale if scale is not None else 1.0 / math.sqrt(d)
+    if (key_padding_mask is None and _fused(q, k, v) and d in (64, 128) and h % hk == 0
+            and (not causal or q_offset >= 0)):
+        return _Attention.apply(q, k, v, causal, scale, q_offset)
     qt, kt, vt = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
     if hk != h:
         kt = kt.repeat_interleave(h // hk, dim=1)

@@ -129,7 +129,9 @@ class GenerationEngine:
         self.done = torch.zeros(B, **i32)
         self.cur_token = torch.zeros(B, **i32)
         self.sampled = torch.zeros(B, **i32)
-        self.sd_result = torch.zeros(4, **i32)  # [n_accepted, next_token, n_emitted, -]
+        self.sd_result = torch.zeros(8, **i32)  # [n_accepted, next_token, n_emitted, step, done, pos, -, -]
+        self.sd_limit = None     # device int32 [1]: freeze verify rounds once this many tokens are out
+        self.sd_stats = None     # device int32 [4]: drafted, accepted, rounds (device-resident SD loops)
         # per-sequence "may advance" flags read by the commit kernel; None = all.  A batch
         # scheduler allocates them (TensorParallelEngine.enable_slot_masks).
         self.active = None
@@ -423,7 +425,8 @@ class GenerationEngine:
         hn = raw.rmsnorm(h, self.final_norm, self.eps)
         pv, pi = raw.linear_argmax_partials(hn.view(G + 1, self.H), self.lm_head, None)
         raw.verify_accept(pv, pi, draft, G, self.out_tokens, self.step, self.pos, self.done,
-                          self.cur_token, self.sd_result, self.eos, self.embed, self.x)
+                          self.cur_token, self.sd_result, self.eos, self.embed, self.x,
+                          self.sd_limit, self.sd_stats)
         return hn.view(G + 1, self.H)
 
     # ------------------------------------------------------------ decode step
