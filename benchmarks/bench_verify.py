@@ -46,3 +46,26 @@ t_unf = timeit(ver)
 print(f"verify(G={G}) unfused={t_unf:.3f} ms", flush=True)
 print(f"layers={cfg.num_hidden_layers} kv_len={L} decode_step={t_dec:.3f} ms  verify(G={G})={t_ver:.3f} ms  "
       f"ratio={t_ver / t_dec:.2f}", flush=True)
+
+# ---- speculative-decoding rounds end to end: draft head (B1 adapter from the verifier's own
+# hidden state, gamma = 1) + verify + accept, host-driven vs device-resident rounds
+from eventgpt_amd import ops  # noqa: E402
+from eventgpt_amd.align.adapters import create_adapter  # noqa: E402
+from eventgpt_amd.runtime.spec_decode import AdapterDraftHead, SpecDecodeEngine  # noqa: E402
+
+eng.fused_rows = 32
+eng._verify_graphs.clear()
+torch.manual_seed(0)
+adapter = create_adapter(5, cfg.hidden_size).to(dev).to(torch.bfloat16)
+head = AdapterDraftHead(adapter, model.lm_head.weight.data)
+sd = SpecDecodeEngine(eng, head, gamma=5)
+n_tok = 48
+for label, dl in (("host loop", False), ("device loop", True)):
+    for rep in range(2):        # first repetition captures the graphs
+        eng.reset(); eng.eos = -1
+        h = eng.prefill(emb, select="greedy", return_hidden=True)
+        vh0 = ops.rmsnorm(h[-1:], eng.final_norm, eng.eps)
+        toks, st = sd.run(None, n_tok, -1, "vlm_only", vh0, device_loop=dl)
+    print(f"SD rounds ({label}, B1 gamma=1): {st.decode_ms:.1f} ms for {st.tokens} tokens, {st.iterations} rounds: "
+          f"{st.decode_ms / max(st.iterations, 1):.3f} ms/round, {st.decode_ms / max(st.tokens, 1):.3f} ms/token "
+          f"(decode step {t_dec:.3f} ms), accept {st.accept_rate:.2f}", flush=True)

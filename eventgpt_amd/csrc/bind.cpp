@@ -862,6 +862,18 @@ Tensor gather_rows_dev(const Tensor& src, const Tensor& index, int64_t offset, c
   return out;
 }
 
+// embeds [B,L,H]: row (b,l) = embed[map] / feats[-1 - map] / zeros (map <= -2^30), see splice_rows_kernel
+Tensor splice_rows(const Tensor& embed, const Tensor& feats, const Tensor& map) {
+  check_bf16(embed, "embed"); check_bf16(feats, "feats"); check_i32(map, "map");
+  TORCH_CHECK(embed.dim() == 2 && feats.dim() == 2 && feats.size(1) == embed.size(1) && embed.size(1) % 8 == 0 &&
+              feats.size(0) >= 1 && map.dim() == 2, "splice_rows: embed [V,H], feats [R,H], map [B,L]");
+  Tensor out = at::empty({map.size(0), map.size(1), embed.size(1)}, embed.options());
+  if (map.numel() > 0)
+    evgpt::launch_splice_rows(bptr(embed), (int)embed.size(0), bptr(feats), (int)feats.size(0), map.data_ptr<int>(),
+                              -(1 << 30), bptr_mut(out), map.numel(), (int)embed.size(1), cur_stream());
+  return out;
+}
+
 void argmax_from_partials(const Tensor& pval, const Tensor& pidx, const Tensor& token, int64_t vocab) {
   check_f32(pval, "pval"); check_i32(pidx, "pidx"); check_i32(token, "token");
   TORCH_CHECK(pval.dim() == 2 && pidx.sizes() == pval.sizes() && token.numel() >= pval.size(0) && vocab >= 1);
@@ -946,6 +958,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("patchify(Tensor px, int P) -> Tensor", &patchify);
   m.def("vit_embed_ln(Tensor tok, Tensor cls, Tensor pos, Tensor w, Tensor b, float eps) -> Tensor", &vit_embed_ln);
   m.def("verify_accept(Tensor pval, Tensor pidx, Tensor draft, int G, Tensor(a!) out_tokens, Tensor(b!) step, Tensor(c!) pos, Tensor(d!) done, Tensor(e!) cur_token, Tensor(f!) result, int eos, Tensor embed, Tensor(g!) x, Tensor? limit=None, Tensor(h!)? stats=None) -> ()", &verify_accept);
+  m.def("splice_rows(Tensor embed, Tensor feats, Tensor map) -> Tensor", &splice_rows);
   m.def("gather_rows_dev(Tensor src, Tensor index, int offset, Tensor? n_valid, int rows) -> Tensor", &gather_rows_dev);
   m.def("argmax_from_partials(Tensor pval, Tensor pidx, Tensor(a!) token, int vocab) -> ()", &argmax_from_partials);
   m.def("attn_d512(Tensor q, Tensor k, Tensor v, bool causal, float scale) -> Tensor", &attn_d512);

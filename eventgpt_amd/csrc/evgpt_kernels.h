@@ -79,6 +79,8 @@ void launch_gather_rows_dev(const bf16_t* src, const int* index, int offset, con
                             int n_rows_src, bf16_t* out, int rows, int H, hipStream_t st);
 void launch_argmax_from_partials(const float* pval, const int* pidx, int rows, int n_part, int* token,
                                  int vocab, hipStream_t st);
+void launch_splice_rows(const bf16_t* embed, int vocab, const bf16_t* feats, int n_feat, const int* map,
+                        int pad, bf16_t* out, long long rows, int H, hipStream_t st);
 void launch_attn_d512(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, long long sb,
                       long long ss, int B, int S, int H, int causal, float scale, hipStream_t st);
 

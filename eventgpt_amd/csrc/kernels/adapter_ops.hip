@@ -65,6 +65,28 @@ void launch_argmax_from_partials(const float* pval, const int* pidx, int rows, i
   hipLaunchKernelGGL(argmax_from_partials_kernel, dim3(rows), dim3(64), 0, st, pval, pidx, n_part, token, vocab);
 }
 
+// Multimodal splice: out[i][:] = embed[map[i]] (map >= 0), feats[-1 - map[i]] (negative) or
+// zeros (padding, map <= pad).  One block per output row; the layout itself (which position
+// takes which row) is a few dozen integers computed by the host from the prompt ids.
+__global__ __launch_bounds__(256) void splice_rows_kernel(const bf16_t* __restrict__ embed, int vocab,
+                                                          const bf16_t* __restrict__ feats, int n_feat,
+                                                          const int* __restrict__ map, int pad,
+                                                          bf16_t* __restrict__ out, int H) {
+  const long long i = blockIdx.x;
+  const int m = map[i];
+  const bf16_t* src = nullptr;
+  if (m >= 0) src = embed + static_cast<size_t>(m < vocab ? m : vocab - 1) * H;
+  else if (m > pad) { const int r = -1 - m; src = feats + static_cast<size_t>(r < n_feat ? r : n_feat - 1) * H; }
+  for (int c = threadIdx.x; c < (H >> 3); c += 256)
+    *reinterpret_cast<u32x4_t*>(out + i * H + c * 8) = src ? load16(src + c * 8) : u32x4_t{0, 0, 0, 0};
+}
+
+void launch_splice_rows(const bf16_t* embed, int vocab, const bf16_t* feats, int n_feat, const int* map,
+                        int pad, bf16_t* out, long long rows, int H, hipStream_t st) {
+  hipLaunchKernelGGL(splice_rows_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0, st, embed, vocab, feats,
+                     n_feat, map, pad, out, H);
+}
+
 // q/k/v: element (b, s, h, d) at base + b*sb + s*ss + h*512 + d (any strides with contiguous d,
 // e.g. the q / k / v thirds of a packed in-projection); out [B][S][H][512] contiguous.
 __global__ __launch_bounds__(256) void attn_d512_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,

@@ -113,6 +113,15 @@ __device__ __forceinline__ bf16x8_t frag_t(const unsigned char* tile, int cb, in
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// 16 bytes per lane from `src + voff` (range-checked against `bytes`: past it, zeros) straight
+// into LDS at `lds + 16 * lane`.  Kept out of the kernel template: the descriptor type exists
+// only in the device pass, and a template body the host pass cannot instantiate loses its
+// launch stub.
+__device__ __forceinline__ void buffer_to_lds16(const unsigned char* src, int bytes, unsigned char* lds, int voff) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(src), 0, bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds, 16, voff, 0, 0, 0);
+}
+
 template <int BM, int BN, int WGM, int WGN, int STAGES, bool AT = false, bool BT = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   static_assert(!AT || BM == 64 || BM == 128, "K-strided A needs a 64- or 128-row tile");
@@ -183,21 +192,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const long long adv_a = AT ? 2ll * k0 * p.lda : 2ll * k0;
     const long long adv_w = BT ? 2ll * k0 * p.ldw : 2ll * k0;
     const long long left_a = bytes_a - adv_a, left_w = bytes_w - adv_w;
-    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.A)) + adv_a, 0,
-        static_cast<int>(left_a > 0 ? left_a : 0), 0x00020000);
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.W)) + adv_w, 0,
-        static_cast<int>(left_w > 0 ? left_w : 0), 0x00020000);
+    const int lim_a = static_cast<int>(left_a > 0 ? left_a : 0), lim_w = static_cast<int>(left_w > 0 ? left_w : 0);
+    const unsigned char* src_a = reinterpret_cast<const unsigned char*>(p.A) + adv_a;
+    const unsigned char* src_w = reinterpret_cast<const unsigned char*>(p.W) + adv_w;
 #pragma unroll
     for (int i = 0; i < BM / 32; ++i) {  // BM/8 row-groups over 4 waves
       const int rg = wid_u * (BM / 32) + i;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(base + rg * 1024), 16, voff_a[i], 0, 0, 0);
+      buffer_to_lds16(src_a, lim_a, base + rg * 1024, voff_a[i]);
     }
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) {
       const int rg = wid_u * (BN / 32) + i;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(base + A_BYTES + rg * 1024), 16, voff_w[i], 0, 0, 0);
+      buffer_to_lds16(src_w, lim_w, base + A_BYTES + rg * 1024, voff_w[i]);
     }
   };
 

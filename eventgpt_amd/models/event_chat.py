@@ -14,8 +14,11 @@ API surface kept from the reference so user code can switch over
 
 Differences by design:
   * all frames of all samples go through the vision tower as ONE batch;
-  * the splice is computed from segment lengths (no per-sample ``tolist`` on the
-    single-event fast path);
+  * the splice is ONE gather: the host lays out, from the prompt ids, which embedding-table
+    row or event-feature row every output position takes (``splice_plan``; the only device
+    read is the copy of the ids themselves when they live on the GPU), and one kernel
+    (``splice_rows``) fills the padded ``[B, L, H]`` batch -- no per-sample ``cat``,
+    ``nonzero`` or ``int(sum)`` round trips;
   * ``event_features`` takes ``already_adapted`` — the reference applies
     ``feature_adaptor`` to cached features even when the caller already did
     (model/EventChatModel.py:346-353); the default reproduces that, the flag
@@ -161,6 +164,62 @@ class EventChatLlamaModel(LlamaModel):
             sd = torch.load(src, map_location="cpu", weights_only=True)
             sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
             getattr(self, module).load_state_dict(sd, strict=True)
+
+
+_PAD = -(1 << 30)     # splice map value of a padding position
+
+
+def splice_plan(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], feat_rows: Sequence[int]):
+    """Layout of the multimodal splice, computed on the host from CPU tensors.
+
+    ``input_ids [B, L]`` hold ``EVENT_TOKEN_INDEX`` where an event goes; the j-th placeholder
+    (counted over the batch in order; a sample WITHOUT a placeholder also consumes one entry,
+    as in the reference, model/EventChatModel.py:371-413) is replaced by ``feat_rows[j]`` rows.
+    Returns ``(src [B, Lmax] int64, label_src [B, Lmax] int64, lengths)``: ``src >= 0`` is a
+    token id to embed, ``-1 - r`` is row ``r`` of the concatenated event features, ``_PAD``
+    is right padding; ``label_src`` is the flat index into ``labels`` (``-1`` = IGNORE_INDEX).
+    Rows are truncated to ``MAX_MULTIMODAL_LENGTH``."""
+    ids = input_ids.long()
+    bsz, length = ids.shape
+    keep = torch.ones_like(ids, dtype=torch.bool) if attention_mask is None else attention_mask.bool()
+    starts = [0]
+    for r in feat_rows:
+        starts.append(starts[-1] + int(r))
+    rows, labs = [], []
+    ev_i = 0
+    for b in range(bsz):
+        sel = torch.nonzero(keep[b]).flatten()
+        row_ids = ids[b][sel]
+        flat_idx = sel + b * length
+        is_ev = row_ids == EVENT_TOKEN_INDEX
+        if not bool(is_ev.any()):
+            rows.append(row_ids)
+            labs.append(flat_idx)
+            ev_i += 1
+            continue
+        pieces, lpieces, prev = [], [], 0
+        for cut in torch.nonzero(is_ev).flatten().tolist():
+            pieces.append(row_ids[prev:cut])
+            lpieces.append(flat_idx[prev:cut])
+            if ev_i >= len(feat_rows):
+                raise ValueError("more <event> placeholders than event features")
+            n = starts[ev_i + 1] - starts[ev_i]
+            pieces.append(-1 - torch.arange(starts[ev_i], starts[ev_i] + n))
+            lpieces.append(torch.full((n,), -1, dtype=torch.long))
+            ev_i += 1
+            prev = cut + 1
+        pieces.append(row_ids[prev:])
+        lpieces.append(flat_idx[prev:])
+        rows.append(torch.cat(pieces)[:MAX_MULTIMODAL_LENGTH])
+        labs.append(torch.cat(lpieces)[:MAX_MULTIMODAL_LENGTH])
+    lengths = [int(r.shape[0]) for r in rows]
+    max_len = max(lengths)
+    src = torch.full((bsz, max_len), _PAD, dtype=torch.long)
+    lab = torch.full((bsz, max_len), -1, dtype=torch.long)
+    for b, (r, l) in enumerate(zip(rows, labs)):
+        src[b, :r.shape[0]] = r
+        lab[b, :l.shape[0]] = l
+    return src, lab, lengths
 
 
 class EventChatModel(nn.Module):
@@ -336,56 +395,41 @@ class EventChatModel(nn.Module):
 
         had_labels, had_mask, had_pos = labels is not None, attention_mask is not None, \
             position_ids is not None
-        mask = torch.ones_like(input_ids, dtype=torch.bool) if attention_mask is None \
-            else attention_mask.bool()
-        if labels is None:
-            labels = torch.full_like(input_ids, IGNORE_INDEX)
+        feats = list(event_features) if isinstance(event_features, (list, tuple)) else \
+            [event_features[i] for i in range(event_features.shape[0])]
         embed = self.get_model().embed_tokens
-
-        rows, row_labels = [], []
-        ev_i = 0
-        for b in range(input_ids.shape[0]):
-            ids, lab = input_ids[b][mask[b]], labels[b][mask[b]]
-            is_ev = ids == EVENT_TOKEN_INDEX
-            n_ev = int(is_ev.sum())
-            if n_ev == 0:
-                rows.append(embed(ids))
-                row_labels.append(lab)
-                ev_i += 1
-                continue
-            text = embed(ids.masked_fill(is_ev, 0))
-            cuts = [-1] + torch.nonzero(is_ev).flatten().tolist() + [ids.shape[0]]
-            pieces, lab_pieces = [], []
-            for j in range(n_ev + 1):
-                pieces.append(text[cuts[j] + 1:cuts[j + 1]])
-                lab_pieces.append(lab[cuts[j] + 1:cuts[j + 1]])
-                if j < n_ev:
-                    feat = event_features[ev_i].to(device=text.device, dtype=text.dtype)
-                    ev_i += 1
-                    pieces.append(feat)
-                    lab_pieces.append(torch.full((feat.shape[0],), IGNORE_INDEX,
-                                                 dtype=lab.dtype, device=lab.device))
-            rows.append(torch.cat(pieces)[:MAX_MULTIMODAL_LENGTH])
-            row_labels.append(torch.cat(lab_pieces)[:MAX_MULTIMODAL_LENGTH])
-
-        max_len = max(r.shape[0] for r in rows)
-        bsz = len(rows)
-        embeds = rows[0].new_zeros(bsz, max_len, rows[0].shape[1])
-        out_labels = torch.full((bsz, max_len), IGNORE_INDEX, dtype=labels.dtype,
-                                device=labels.device)
-        out_mask = torch.zeros(bsz, max_len, dtype=torch.bool, device=input_ids.device)
-        out_pos = torch.zeros(bsz, max_len, dtype=torch.long, device=input_ids.device)
-        for b, (r, l) in enumerate(zip(rows, row_labels)):  # right padding
-            n = r.shape[0]
-            embeds[b, :n] = r
-            out_labels[b, :n] = l
-            out_mask[b, :n] = True
-            out_pos[b, :n] = torch.arange(n, device=out_pos.device)
+        dev = embed.weight.device
+        # layout on the host: ids are a few dozen integers (one copy if they live on the device)
+        ids_h = input_ids.detach().cpu()
+        mask_h = None if attention_mask is None else attention_mask.detach().bool().cpu()
+        src, lab_src, lengths = splice_plan(ids_h, mask_h, [int(f.shape[0]) for f in feats])
+        bsz, max_len = src.shape
+        used = int((src < 0).logical_and(src > _PAD).sum()) > 0
+        feat_cat = torch.cat([f.to(device=dev, dtype=embed.weight.dtype) for f in feats]) if used else \
+            embed.weight.new_zeros(1, embed.weight.shape[1])
+        src_d = src.to(dev)
+        needs_grad = torch.is_grad_enabled() and (embed.weight.requires_grad or feat_cat.requires_grad)
+        if dev.type == "cuda" and embed.weight.dtype == torch.bfloat16 and not needs_grad:
+            from ..ops import hip
+            embeds = hip.raw.splice_rows(embed.weight.detach(), feat_cat.detach().contiguous(),
+                                         src_d.to(torch.int32).contiguous())
+        else:
+            tok = embed(src_d.clamp(min=0))
+            ev = feat_cat[(-1 - src_d).clamp(min=0, max=feat_cat.shape[0] - 1)]
+            embeds = torch.where((src_d >= 0)[..., None], tok, ev)
+            embeds = embeds * (src_d > _PAD)[..., None].to(embeds.dtype)
+        # labels / mask / positions follow the same layout (host arithmetic, one upload each)
+        out_mask = (src > _PAD)
+        out_labels = None
+        if had_labels:
+            lab_h = labels.detach().cpu()
+            flat = torch.cat([lab_h.reshape(-1), lab_h.new_full((1,), IGNORE_INDEX)])
+            out_labels = flat[lab_src.clamp(min=-1)].reshape(bsz, max_len).to(labels.device)
+        out_pos = (torch.arange(max_len)[None].expand(bsz, max_len) * out_mask).to(input_ids.device)
         return (None,
                 out_pos if had_pos else None,
-                out_mask.to(attention_mask.dtype) if had_mask else None,
-                past_key_values, embeds,
-                out_labels if had_labels else None)
+                out_mask.to(device=input_ids.device, dtype=attention_mask.dtype) if had_mask else None,
+                past_key_values, embeds, out_labels)
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids=None, attention_mask=None, position_ids=None,

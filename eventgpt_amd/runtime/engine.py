@@ -223,6 +223,20 @@ class GenerationEngine:
     def reset(self) -> None:
         for t in (self.step, self.pos, self.done, self.cur_token):
             t.zero_()
+        self._pos_hi = 0
+
+    # Host-side upper bound of the device position counters.  The kernels clamp a position that
+    # runs past the cache (nothing faults), but a clamped verify silently accepts or emits wrong
+    # tokens, so multi-row passes are refused on the host before they can overrun: the bound is
+    # advanced by the most a call can append and re-read exactly (one small copy) only when it
+    # says the cache might be full.
+    _pos_hi = 0
+
+    def cache_room(self, rows: int) -> bool:
+        """True if ``rows`` more positions fit the cache of every sequence."""
+        if self._pos_hi + rows > self.l_max:
+            self._pos_hi = int(self.pos.max().item())
+        return self._pos_hi + rows <= self.l_max
 
     @property
     def kv_bytes_per_token(self) -> int:
@@ -254,6 +268,7 @@ class GenerationEngine:
             raise ValueError(f"sequence of {start + S} tokens exceeds the cache ({self.l_max})")
         pos0 = torch.tensor([start], dtype=torch.int32, device=self.device)
         x = self._forward_rows(embeds, batch, pos0)
+        self._pos_hi = max(self._pos_hi, start + S)
         if select is None:
             self.pos[batch] = start + S
         else:
@@ -395,6 +410,10 @@ class GenerationEngine:
         G = int(draft.shape[0]) if n_draft is None else int(n_draft)
         if G < 1 or G > 63:
             raise ValueError(f"verify takes 1..63 draft tokens, got {G}")
+        if not self.cache_room(G + 1):
+            raise ValueError(f"verify of {G} draft tokens at position {self._pos_hi} does not fit the cache "
+                             f"({self.l_max}); fall back to decode_step or stop")
+        self._pos_hi += G + 1
         draft = draft[:G].to(torch.int32)
         if not self.use_graph:
             hn = self._verify_body(draft.contiguous(), G)
@@ -525,6 +544,7 @@ class GenerationEngine:
 
     def decode_step(self, greedy: bool = True) -> None:
         """Advance every sequence by one token (graph replay when enabled)."""
+        self._pos_hi += 1
         if not self.use_graph:
             (self._step_greedy if greedy else self._step_logits)()
             return

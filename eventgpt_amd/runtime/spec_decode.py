@@ -17,9 +17,18 @@ Pieces (reference counterparts in brackets):
 
 Every verify step is ``GenerationEngine.verify``: one forward over gamma+1 rows
 and a fused accept kernel; acceptance, the bonus token, EOS and KV rollback
-happen on the device.  The host reads back three integers per round for
-statistics and loop control.  Output is lossless: the emitted sequence equals
-the verifier's own greedy decode.
+happen on the device.  Output is lossless: the emitted sequence equals the
+verifier's own greedy decode.
+
+Device-resident rounds (``SpecDecodeEngine.run(..., device_loop=True)``, the default on
+a GPU when the adapter has a kernel forward): one round -- gather the drafter rows that
+belong to the current position (the position is a device counter), adapter forward on
+the in-tree kernels, lm_head GEMM with argmax epilogue, verify forward, accept kernel --
+is ONE captured hipGraph.  The host replays it ``poll_every`` times back to back and
+then reads six integers; rounds that land after the sequence finished change nothing
+(the accept kernel freezes once ``done`` is set or the token budget is out).  The
+reference's loop synchronises several times per round (``.tolist()`` of the argmax,
+Python prefix match, KV slicing: benchmark_e2e_wallclock.py:569-637, 860-1032).
 """
 from __future__ import annotations
 
@@ -69,6 +78,24 @@ class AdapterDraftHead:
         self.dtype = next(adapter.parameters()).dtype
         self.w = lm_head_weight
         self._w_bf16 = None
+        self.kernels = None
+        if lm_head_weight.is_cuda and lm_head_weight.shape[1] % 64 == 0:
+            from ..align.adapter_engine import AdapterKernels
+            if AdapterKernels.supports(adapter):
+                self.kernels = AdapterKernels(adapter)
+
+    @torch.no_grad()
+    def draft_device(self, hidden: torch.Tensor, verifier_hidden: Optional[torch.Tensor],
+                     out: torch.Tensor) -> None:
+        """Draft tokens of ``hidden [G,H]`` into ``out`` (device int32 ``[G]``) on in-tree kernels
+        only: no allocation through a library workspace, no host sync -- safe to record into
+        the graph of a draft/verify round."""
+        from ..ops import hip
+        if self._w_bf16 is None:
+            self._w_bf16 = self.w.to(torch.bfloat16).contiguous()
+        aligned = self.kernels(hidden, verifier_hidden)
+        pv, pi = hip.raw.linear_argmax_partials(aligned, self._w_bf16, None)
+        hip.raw.argmax_from_partials(pv, pi, out, int(self._w_bf16.shape[0]))
 
     @torch.no_grad()
     def __call__(self, hidden: torch.Tensor, verifier_hidden: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -107,14 +134,22 @@ class NaiveSpeculativeDecoder:
         target_embeds = draft_embeds if target_embeds is None else target_embeds
         d.eos = t.eos = eos_token_id
         d.reset(); t.reset()
+        gamma = num_draft_tokens
+        # every verify appends up to gamma+1 cache rows on both sides: keep the budget inside
+        room = min(t.l_max - target_embeds.shape[0], d.l_max - draft_embeds.shape[0]) - (gamma + 1)
+        if room < 1:
+            raise ValueError(f"prompt of {target_embeds.shape[0]} / {draft_embeds.shape[0]} tokens leaves no room "
+                             f"for speculative rounds of {gamma} in caches of {t.l_max} / {d.l_max}")
+        max_new_tokens = min(max_new_tokens, room)
         t.prefill(target_embeds, select="greedy")          # first token comes from the target
         d.prefill(draft_embeds, select=None)
         offset = draft_embeds.shape[0] - target_embeds.shape[0]
         history: List[float] = []
-        gamma = num_draft_tokens
-        while int(t.step[0].item()) < max_new_tokens and not int(t.done[0].item()):
+        # one read per round: [n_accepted, next, emitted, step, done, pos] of the last verify
+        info = [0, 0, 0, 1, int(t.done[0].item()), target_embeds.shape[0]]
+        while info[3] < max_new_tokens and not info[4]:
             # drafter continues from the target's current token at its own position
-            base = int(t.pos[0].item()) + offset
+            base = info[5] + offset
             d.pos.fill_(base)
             d.step.zero_()
             d.x[0].copy_(d.embed[t.cur_token[0].long()])
@@ -122,9 +157,10 @@ class NaiveSpeculativeDecoder:
                 d.decode_step(True)
             draft = d.out_tokens[0, :gamma].clone()
             t.verify(draft, gamma)
-            n_acc = int(t.sd_result[0].item())
+            info = t.sd_result[:6].tolist()
+            n_acc = info[0]
             history.append(n_acc / gamma)
-            if n_acc == gamma and not int(t.done[0].item()):
+            if n_acc == gamma and not info[4]:
                 # every draft token was accepted: the drafter has not yet ingested the
                 # last one (its cache holds pos < base+gamma)
                 d.pos.fill_(base + gamma)
@@ -141,6 +177,107 @@ class SpecDecodeEngine:
         self.v = verifier_engine
         self.head = draft_head
         self.gamma = gamma
+        self._round_graphs = {}        # (mode, G, eos) -> captured draft/verify round
+        self._dh = None                # static copy of the drafter states the rounds gather from
+        self._nh = None
+
+    # ------------------------------------------------------ device-resident rounds
+    def device_loop_available(self) -> bool:
+        v = self.v
+        return bool(self.head is not None and self.head.kernels is not None and v.device.type == "cuda"
+                    and v.B == 1 and v.H % 64 == 0)
+
+    def _round_state(self, G: int, n_rows: int):
+        v, dev = self.v, self.v.device
+        if self._dh is None or self._dh.shape[0] < max(n_rows, 1):
+            self._dh = torch.zeros(max(n_rows, v.max_out, 64), v.H, dtype=torch.bfloat16, device=dev)
+            self._nh = torch.ones(1, dtype=torch.int32, device=dev)
+            self._round_graphs.clear()       # graphs bake the buffer addresses
+        if getattr(self, "_vh", None) is None:
+            self._vh = torch.zeros(64, v.H, dtype=torch.bfloat16, device=dev)
+            self._draft = torch.zeros(63, dtype=torch.int32, device=dev)
+        if v.sd_limit is None:
+            v.sd_limit = torch.zeros(1, dtype=torch.int32, device=dev)
+            v.sd_stats = torch.zeros(4, dtype=torch.int32, device=dev)
+            v._verify_graphs.clear()         # earlier verify graphs were captured without them
+
+    def _round_body(self, mode: str, G: int) -> None:
+        from ..ops import hip
+        raw, v = hip.raw, self.v
+        draft = self._draft[:G]
+        if mode == "adapter":
+            rows = raw.gather_rows_dev(self._dh, v.step, -1, self._nh, G)
+            self.head.draft_device(rows, None, draft)
+        else:
+            vh = raw.gather_rows_dev(self._vh, v.sd_result, 0, None, 1)   # the row that predicts the next token
+            if mode == "vlm_only":
+                self.head.draft_device(vh, None, draft)
+            else:
+                rows = raw.gather_rows_dev(self._dh, v.step, -1, self._nh, 1)
+                self.head.draft_device(rows, vh, draft)
+        hn = v._verify_body(draft, G)
+        if mode != "adapter":
+            self._vh[:G + 1].copy_(hn)
+
+    def _round_graph(self, mode: str, G: int):
+        v = self.v
+        key = (mode, G, v.eos)
+        g = self._round_graphs.get(key)
+        if g is None:
+            keep_t = (v.out_tokens, v.sd_result, v.sd_stats, self._vh)
+            keep = [t.clone() for t in keep_t]
+            try:
+                g = v._capture(lambda: self._round_body(mode, G))
+            finally:
+                for t, k in zip(keep_t, keep):
+                    t.copy_(k)
+            self._round_graphs[key] = g
+        return g
+
+    @torch.no_grad()
+    def _run_device(self, drafter_hidden, max_new_tokens, mode, verifier_prefill_hidden, poll_every, stats):
+        v = self.v
+        need_vh = mode in ("vlm_only", "fused")
+        G = 1 if need_vh else self.gamma
+        n_h = 0 if drafter_hidden is None else int(drafter_hidden.shape[0])
+        self._round_state(G, n_h)
+        if n_h:
+            self._dh[:n_h].copy_(drafter_hidden.to(torch.bfloat16))
+        self._nh.fill_(max(n_h, 1))
+        start = v.sd_result.new_tensor([0, 0, 0, 0, 0, 0, 0, 0])
+        v.sd_result.copy_(start)
+        if need_vh:
+            self._vh[0].copy_(verifier_prefill_hidden.reshape(-1).to(torch.bfloat16))
+        step0, pos0 = int(v.step[0].item()), int(v.pos[0].item())
+        # every round (also one that lands after the end) writes G+1 cache rows at the position
+        budget = min(max_new_tokens, step0 + (v.l_max - pos0) - (G + 1))
+        if budget <= step0:
+            raise ValueError(f"no room for speculative rounds of {G} at position {pos0} in a cache of {v.l_max}")
+        v.sd_limit.fill_(budget)
+        v.sd_stats.zero_()
+        graph = self._round_graph(mode, G) if v.use_graph else None
+        step, done = step0, int(v.done[0].item())
+        while step < budget and not done:
+            if mode == "adapter" and step - 1 >= n_h:       # drafter states used up: plain decoding
+                for _ in range(min(poll_every, budget - step)):
+                    v.decode_step(True)
+                    stats.fallback_steps += 1
+                    stats.iterations += 1
+                step, done = int(v.step[0].item()), int(v.done[0].item())
+                continue
+            for _ in range(min(poll_every, budget - step)):  # a round emits at least one token
+                if graph is not None:
+                    graph.replay()
+                else:
+                    self._round_body(mode, G)
+            info = v.sd_result[:6].tolist()                  # the only host read of these rounds
+            step, done = info[3], info[4]
+        st = v.sd_stats.tolist()
+        stats.total_drafted += st[0]
+        stats.total_accepted += st[1]
+        stats.iterations += st[2]
+        v.sd_limit.fill_(1 << 30)
+        v._pos_hi = int(v.pos[0].item())
 
     # ---------------------------------------------------------------- drafting
     def _verify(self, draft: torch.Tensor, stats: SDStats, want_hidden: bool):
@@ -160,7 +297,8 @@ class SpecDecodeEngine:
     @torch.no_grad()
     def run(self, drafter_hidden: Optional[torch.Tensor], max_new_tokens: int = 50,
             eos_token_id: int = 2, mode: str = "adapter",
-            verifier_prefill_hidden: Optional[torch.Tensor] = None) -> tuple:
+            verifier_prefill_hidden: Optional[torch.Tensor] = None,
+            device_loop: Optional[bool] = None, poll_every: int = 4) -> tuple:
         """SD decode after the verifier has prefilled and committed its first token.
 
         ``drafter_hidden [N, H]``: the drafter's per-step last-layer hidden states
@@ -168,6 +306,10 @@ class SpecDecodeEngine:
         ``mode``: ``"adapter"`` (L1-L5, one-shot gamma drafts), ``"vlm_only"`` (B1,
         gamma=1 from the verifier's own last hidden state) or ``"fused"`` (L5F,
         gamma=1 from drafter + verifier hidden).  Returns ``(tokens, SDStats)``.
+
+        ``device_loop`` (default: on when the adapter has a kernel forward): rounds are
+        captured graphs replayed ``poll_every`` at a time with one host read per batch of
+        rounds; off, every round is driven and read back by the host.
         """
         v = self.v
         v.eos = eos_token_id
@@ -175,6 +317,19 @@ class SpecDecodeEngine:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         need_vh = mode in ("vlm_only", "fused")
+        if device_loop is None:
+            device_loop = self.device_loop_available() and (not need_vh or verifier_prefill_hidden is not None) \
+                and (mode != "fused" or drafter_hidden is not None)
+        if device_loop:
+            self._run_device(drafter_hidden, max_new_tokens, mode, verifier_prefill_hidden, poll_every, stats)
+            torch.cuda.synchronize()
+            stats.decode_ms = (time.perf_counter() - t0) * 1e3
+            toks = _emitted(v)[:max_new_tokens]
+            stats.tokens = int(toks.shape[0])
+            return toks, stats
+        # cache room: a verify appends up to gamma+1 rows
+        room = v.l_max - int(v.pos[0].item()) - ((1 if need_vh else self.gamma) + 1)
+        max_new_tokens = min(max_new_tokens, int(v.step[0].item()) + max(room, 0))
         last_vh = verifier_prefill_hidden  # [1, H] verifier hidden that predicts the next token
         n_h = 0 if drafter_hidden is None else drafter_hidden.shape[0]
         while True:
