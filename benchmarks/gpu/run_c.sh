@@ -14,13 +14,9 @@ step() {  # step <limit_s> <log> <cmd...>
   return $rc
 }
 PT="python -u -m pytest -x -v --timeout 120 --timeout-method thread"
-step 600 t_ops.log $PT tests/test_ops_gpu.py -q || { tail -40 gpurun_out/t_ops.log; exit 1; }
-tail -2 gpurun_out/t_ops.log
-step 600 t_train.log $PT tests/test_train_kernels_gpu.py || { tail -40 gpurun_out/t_train.log; exit 1; }
-tail -2 gpurun_out/t_train.log
-step 600 t_adapter.log $PT tests/test_adapter_kernels_gpu.py tests/test_splice_gpu.py
+step 600 t_adapter.log python -u -m pytest -v --timeout 120 --timeout-method thread tests/test_adapter_kernels_gpu.py tests/test_splice_gpu.py -k 'not match_module and not d512'
 tail -25 gpurun_out/t_adapter.log
-step 900 t_engine.log $PT tests/test_engine_gpu.py tests/test_sd_gpu.py tests/test_w4_gpu.py -q
+step 900 t_engine.log $PT tests/test_engine_gpu.py tests/test_sd_gpu.py tests/test_w4.py tests/test_event_ops_gpu.py tests/test_optim_gpu.py -q -m gpu
 tail -15 gpurun_out/t_engine.log
 step 300 b_default.log python bench.py --steps 128 --warmup 16
 tail -1 gpurun_out/b_default.log

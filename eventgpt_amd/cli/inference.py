@@ -36,6 +36,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--context_len", type=int, default=2048)
     p.add_argument("--temperature", type=float, default=0.6)
     p.add_argument("--top_p", type=float, default=1)
+    p.add_argument("--top_k", type=int, default=50,
+                   help="sampling keeps the k most likely tokens (0 = off); 50 is what the reference's "
+                        "generate() call inherits from its generation defaults")
     p.add_argument("--num_beams", type=int, default=1)
     p.add_argument("--max_new_tokens", type=int, default=512)
     p.add_argument("--spatial_temporal_encoder", type=bool, default=True)
@@ -111,7 +114,7 @@ def run(argv: Optional[Sequence[str]] = None) -> str:
     with torch.inference_mode():
         out = model.generate(input_ids, event_tensors=tensors, event_image_sizes=size,
                              do_sample=args.temperature > 0, temperature=args.temperature,
-                             top_p=args.top_p, num_beams=args.num_beams,
+                             top_p=args.top_p, top_k=args.top_k, num_beams=args.num_beams,
                              max_new_tokens=args.max_new_tokens, use_cache=True, generator=gen)
     text = tokenizer.batch_decode(out, skip_special_tokens=True)[0].strip()
     print(text)

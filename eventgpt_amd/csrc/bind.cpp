@@ -899,13 +899,13 @@ Tensor attn_d512(const Tensor& q, const Tensor& k, const Tensor& v, bool causal,
 }
 
 void sample_top_p(const Tensor& logits, const Tensor& out, double temperature, double top_p,
-                  int64_t seed, const Tensor& step) {
+                  int64_t seed, const Tensor& step, int64_t top_k) {
   check_f32(logits, "logits"); check_i32(out, "out"); check_i32(step, "step");
   TORCH_CHECK(logits.dim() == 2 && logits.size(1) <= 40960 && temperature > 0);
   const int64_t B = logits.size(0);
   TORCH_CHECK(out.numel() >= B && step.numel() >= B);
   evgpt::launch_sample_top_p(logits.data_ptr<float>(), out.data_ptr<int>(), (int)B,
-                             (int)logits.size(1), (float)temperature, (float)top_p,
+                             (int)logits.size(1), (float)temperature, (int)std::max<int64_t>(top_k, 0), (float)top_p,
                              (unsigned long long)seed, step.data_ptr<int>(), cur_stream());
 }
 
@@ -962,6 +962,6 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("gather_rows_dev(Tensor src, Tensor index, int offset, Tensor? n_valid, int rows) -> Tensor", &gather_rows_dev);
   m.def("argmax_from_partials(Tensor pval, Tensor pidx, Tensor(a!) token, int vocab) -> ()", &argmax_from_partials);
   m.def("attn_d512(Tensor q, Tensor k, Tensor v, bool causal, float scale) -> Tensor", &attn_d512);
-  m.def("sample_top_p(Tensor logits, Tensor(a!) out, float temperature, float top_p, int seed, Tensor step) -> ()", &sample_top_p);
+  m.def("sample_top_p(Tensor logits, Tensor(a!) out, float temperature, float top_p, int seed, Tensor step, int top_k=0) -> ()", &sample_top_p);
   m.def("prefill_rope_kv(Tensor qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos0, int Hq, int Hkv, int D) -> ()", &prefill_rope_kv);
 }

@@ -90,7 +90,7 @@ void launch_verify_accept(const float* pval, const int* pidx, int n_part, const 
                           int* cur_token, int* result, int eos, const bf16_t* embed, bf16_t* x,
                           int H, int vocab, hipStream_t st, const int* limit = nullptr,
                           int* stats = nullptr);
-void launch_sample_top_p(const float* logits, int* out, int B, int V, float temperature,
+void launch_sample_top_p(const float* logits, int* out, int B, int V, float temperature, int top_k,
                          float top_p, unsigned long long seed, const int* step,
                          hipStream_t st);
 

@@ -96,11 +96,13 @@ void launch_verify_accept(const float* pval, const int* pidx, int n_part, const 
 }
 
 // ---------------------------------------------------------------- sampler
-// Temperature + nucleus (top-p) sampling of one token per row, entirely on the
-// device: one 1024-thread block per row keeps the row's probabilities in
-// registers, finds the probability threshold whose tail mass reaches top_p by
-// bisection (no sort), then walks the kept set with a counter-based uniform
-// draw.  The random stream is a function of (seed, step[b], row), so replaying
+// Temperature + top-k + nucleus (top-p) sampling of one token per row, entirely
+// on the device: one 1024-thread block per row keeps the row's probabilities in
+// registers, finds the k-th largest probability exactly by bisecting on its bit
+// pattern (positive floats order like their bits; ties at the k-th value are all
+// kept), then the probability threshold whose tail mass reaches top_p of what is
+// left by bisection (no sort), then walks the kept set with a counter-based
+// uniform draw.  The random stream is a function of (seed, step[b], row), so replaying
 // a captured graph still draws fresh numbers as the device-side step advances.
 __device__ __forceinline__ unsigned int mix32(unsigned long long z) {
   z += 0x9E3779B97F4A7C15ull;
@@ -113,7 +115,7 @@ constexpr int SP_THREADS = 1024;
 constexpr int SP_MAX_PER_THREAD = 40;  // vocab up to 40960
 
 __global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(
-    const float* __restrict__ logits, int* __restrict__ out, int V, float inv_temp, float top_p,
+    const float* __restrict__ logits, int* __restrict__ out, int V, float inv_temp, int top_k, float top_p,
     unsigned long long seed, const int* __restrict__ step) {
   __shared__ float red[16];
   __shared__ float scan[SP_THREADS];
@@ -139,7 +141,24 @@ __global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < SP_MAX_PER_THREAD; ++i) { pr[i] = __expf(pr[i] - mx); sum += pr[i]; }
-  const float total = block_sum(sum, red);
+  float total = block_sum(sum, red);
+  if (top_k > 0 && top_k < V) {
+    // largest t with count(bits(p) >= t) >= k; p in [0, 1] so t in [0, bits(1.0f)]
+    unsigned int lo = 0u, hi = 0x3F800000u + 1u;  // invariant: count(>= lo) >= k, count(>= hi) < k
+    while (hi - lo > 1u) {
+      const unsigned int mid = lo + ((hi - lo) >> 1);
+      float c = 0.f;
+#pragma unroll
+      for (int i = 0; i < SP_MAX_PER_THREAD; ++i) c += __float_as_uint(pr[i]) >= mid ? 1.f : 0.f;
+      c = block_sum(c, red);
+      if (c >= static_cast<float>(top_k)) lo = mid; else hi = mid;
+    }
+    const float kth = __uint_as_float(lo);
+    sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SP_MAX_PER_THREAD; ++i) { if (pr[i] < kth) pr[i] = 0.f; sum += pr[i]; }
+    total = block_sum(sum, red);
+  }
   // bisection on the threshold: keep = {p >= thr}; want the largest thr whose
   // kept mass still reaches top_p * total
   float thr = 0.f;
@@ -187,10 +206,10 @@ __global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(
   }
 }
 
-void launch_sample_top_p(const float* logits, int* out, int B, int V, float temperature,
+void launch_sample_top_p(const float* logits, int* out, int B, int V, float temperature, int top_k,
                          float top_p, unsigned long long seed, const int* step, hipStream_t st) {
   hipLaunchKernelGGL(sample_top_p_kernel, dim3(B), dim3(SP_THREADS), 0, st, logits, out, V,
-                     1.f / temperature, top_p, seed, step);
+                     1.f / temperature, top_k, top_p, seed, step);
 }
 
 }  // namespace evgpt

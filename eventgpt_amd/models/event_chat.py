@@ -475,7 +475,7 @@ class EventChatModel(nn.Module):
         return self.generate_from_embeds(inputs_embeds, attention_mask, **kwargs)
 
     def generate_from_embeds(self, inputs_embeds, attention_mask=None, do_sample=False,
-                             temperature=1.0, top_p=1.0, num_beams=1, max_new_tokens=512,
+                             temperature=1.0, top_p=1.0, top_k=50, num_beams=1, max_new_tokens=512,
                              use_cache=True, output_hidden_states=False,
                              return_dict_in_generate=False, eos_token_id=None,
                              generator: Optional[torch.Generator] = None,
@@ -497,7 +497,7 @@ class EventChatModel(nn.Module):
             if not engine_ok:
                 raise ValueError("engine path needs a bf16 GPU batch of one without padding")
             seq = self.engine().generate(inputs_embeds[0], max_new_tokens, temperature, top_p,
-                                         eos, generator)[None]
+                                         eos, generator, top_k or 0)[None]
             return GenerateOutput(seq) if return_dict_in_generate else seq
 
         # module path: dynamic caches, any batch, optional hidden-state capture
@@ -515,7 +515,7 @@ class EventChatModel(nn.Module):
         tokens = []
         for step in range(max_new_tokens):
             logits = self.lm_head(last)
-            nxt = ops.sample_top_p(logits, temperature, top_p, generator) if temperature > 0 \
+            nxt = ops.sample_top_p(logits, temperature, top_p, generator, top_k or 0) if temperature > 0 \
                 else ops.argmax_last(logits)
             nxt = torch.where(done, torch.full_like(nxt, self.config.pad_token_id or 0), nxt)
             tokens.append(nxt)

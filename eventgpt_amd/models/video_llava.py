@@ -288,6 +288,7 @@ class VideoLlavaModel(nn.Module):
     @torch.no_grad()
     def generate(self, input_ids=None, pixel_values_videos=None, attention_mask=None, max_new_tokens: int = 50,
                  do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0, eos_token_id=None,
+                 top_k: int = 50,
                  output_hidden_states: bool = False, return_dict_in_generate: bool = False,
                  use_engine: Optional[bool] = None, generator=None, **unused):
         """Returns only the generated ids ``[B, n_new]`` (prompt goes in as embeddings)."""
@@ -299,7 +300,7 @@ class VideoLlavaModel(nn.Module):
         if use_engine is None:
             use_engine = engine_ok
         if use_engine:
-            seq = self.engine().generate(embeds[0], max_new_tokens, temp, top_p, eos, generator)[None]
+            seq = self.engine().generate(embeds[0], max_new_tokens, temp, top_p, eos, generator, top_k or 0)[None]
             return GenerateOutput(seq) if return_dict_in_generate else seq
         lm = self.language_model
         out = lm.model(inputs_embeds=embeds, use_cache=True, output_hidden_states=output_hidden_states)
@@ -311,7 +312,7 @@ class VideoLlavaModel(nn.Module):
         from .. import ops
         for step in range(max_new_tokens):
             logits = lm.lm_head(last)
-            nxt = ops.sample_top_p(logits, temp, top_p, generator) if temp > 0 else ops.argmax_last(logits)
+            nxt = ops.sample_top_p(logits, temp, top_p, generator, top_k or 0) if temp > 0 else ops.argmax_last(logits)
             nxt = torch.where(done, torch.zeros_like(nxt), nxt)
             toks.append(nxt)
             done = done | (nxt == eos)

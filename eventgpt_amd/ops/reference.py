@@ -155,11 +155,16 @@ def argmax_last(logits: torch.Tensor) -> torch.Tensor:
 
 
 def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float,
-                 generator: Optional[torch.Generator] = None) -> torch.Tensor:
-    """Temperature + nucleus sampling over the last dim; returns ``[...]`` long."""
+                 generator: Optional[torch.Generator] = None, top_k: int = 0) -> torch.Tensor:
+    """Temperature, then top-k (0 = off; ties at the k-th value are kept), then nucleus
+    sampling over the last dim; returns ``[...]`` long."""
     if temperature <= 0:
         return argmax_last(logits)
-    probs = torch.softmax(logits.float() / temperature, dim=-1)
+    scaled = logits.float() / temperature
+    if 0 < top_k < scaled.shape[-1]:
+        kth = scaled.topk(top_k, dim=-1).values[..., -1:]
+        scaled = scaled.masked_fill(scaled < kth, float("-inf"))
+    probs = torch.softmax(scaled, dim=-1)
     if top_p < 1.0:
         sp, si = probs.sort(dim=-1, descending=True)
         cum = sp.cumsum(dim=-1)

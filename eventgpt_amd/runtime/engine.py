@@ -564,19 +564,20 @@ class GenerationEngine:
             self._graph_logits.replay()
 
     # --------------------------------------------------------------- generate
-    def _sample_and_commit(self, temperature: float, top_p: float, generator) -> None:
-        """Draw the next token on the device (bisection top-p kernel keyed by
+    def _sample_and_commit(self, temperature: float, top_p: float, generator, top_k: int = 0) -> None:
+        """Draw the next token on the device (top-k / top-p by bisection, keyed by
         ``(seed, step)``) and commit it; no host round trip."""
         seed = int(generator.initial_seed()) if generator is not None else 0
         self.raw.sample_top_p(self.logits, self.sampled, float(temperature), float(top_p),
-                              seed & 0x7FFFFFFFFFFFFFFF, self.step)
+                              seed & 0x7FFFFFFFFFFFFFFF, self.step, int(top_k))
         self._commit_sampled()
 
     @torch.no_grad()
     def generate(self, embeds: torch.Tensor, max_new_tokens: int = 512, temperature: float = 0.0,
                  top_p: float = 1.0, eos_token_id: Optional[int] = None,
-                 generator: Optional[torch.Generator] = None) -> torch.Tensor:
-        """Greedy / nucleus generation for one sequence; returns new token ids (long).
+                 generator: Optional[torch.Generator] = None, top_k: int = 0) -> torch.Tensor:
+        """Greedy / sampled generation for one sequence; returns new token ids (long).
+        Sampling applies temperature, then ``top_k`` (0 = off), then ``top_p``.
 
         Greedy decoding replays one captured graph per token and syncs with the
         host only every ``poll_every`` tokens to read the EOS flag.  Sampling
@@ -590,14 +591,14 @@ class GenerationEngine:
         greedy = temperature <= 0
         self.prefill(embeds, select="greedy" if greedy else "logits")
         if not greedy:
-            self._sample_and_commit(temperature, top_p, generator)
+            self._sample_and_commit(temperature, top_p, generator, top_k)
         budget = min(max_new_tokens, self.l_max - embeds.shape[0])
-        return self.generate_continue(budget, None, temperature, top_p, generator)
+        return self.generate_continue(budget, None, temperature, top_p, generator, top_k)
 
     @torch.no_grad()
     def generate_continue(self, max_new_tokens: int, eos_token_id: Optional[int] = None,
                           temperature: float = 0.0, top_p: float = 1.0,
-                          generator: Optional[torch.Generator] = None) -> torch.Tensor:
+                          generator: Optional[torch.Generator] = None, top_k: int = 0) -> torch.Tensor:
         """Keep decoding sequence 0 until ``max_new_tokens`` tokens have been emitted in
         total (counting those already committed) or EOS; returns all emitted tokens."""
         if eos_token_id is not None:
@@ -610,7 +611,7 @@ class GenerationEngine:
             for _ in range(chunk):
                 self.decode_step(greedy)
                 if not greedy:
-                    self._sample_and_commit(temperature, top_p, generator)
+                    self._sample_and_commit(temperature, top_p, generator, top_k)
             n += chunk
         toks = self.out_tokens[0, :n].to(torch.long)
         if self.eos >= 0:

@@ -90,16 +90,17 @@ def test_device_rounds_equal_host_rounds_and_greedy(dev, mode, level):
     assert head.kernels is not None
     sd = SpecDecodeEngine(v, head, gamma=4)
     assert sd.device_loop_available()
+    from _lossless import assert_lossless
     outs = {}
     for dl in (False, True, True):                 # the third run replays the graph captured by the second
         v.reset(); v.eos = -1
         h = v.prefill(emb, select="greedy", return_hidden=True)
         vh0 = ops.rmsnorm(h[-1:], v.final_norm, v.eps)
         toks, stats = sd.run(dh["hidden"], 24, -1, mode, vh0, device_loop=dl, poll_every=3)
-        assert torch.equal(toks, greedy[:24]), (dl, toks.tolist(), greedy.tolist())
+        assert_lossless(v, emb, toks, greedy[:24])
         assert stats.total_drafted > 0 and stats.iterations > 0 and stats.tokens == 24
         outs[dl] = stats
-    assert v.graph_captured or True
+    assert outs[True].iterations > 0 and outs[True].total_drafted >= outs[True].total_accepted
 
 
 def test_verify_past_the_cache_is_refused(dev):

@@ -204,3 +204,20 @@ def test_loss_with_labels(tiny):
     labels = torch.tensor([[IGNORE_INDEX, IGNORE_INDEX, 5, 6, 7]])
     out = tiny(input_ids=ids, labels=labels, event_features=torch.randn(1, 3, 64), already_adapted=True)
     assert out.loss is not None and out.loss.item() > 0 and out.logits.shape[1] == 7
+
+
+def test_sampler_top_k_then_top_p_cpu():
+    """The reference op applies temperature, top-k (ties at the k-th value kept), then top-p."""
+    from eventgpt_amd.ops import reference as ref
+    g = torch.Generator().manual_seed(0)
+    logits = torch.full((1, 50), -9.0)
+    logits[0, [3, 10, 20, 30]] = torch.tensor([1.0, 0.5, 0.5, 0.0])
+    seen = {int(ref.sample_top_p(logits, 1.0, 1.0, g, top_k=2)) for _ in range(200)}
+    assert seen == {3, 10, 20}
+    assert {int(ref.sample_top_p(logits, 1.0, 0.4, g, top_k=3)) for _ in range(50)} == {3}
+    assert int(ref.sample_top_p(torch.randn(1, 99, generator=g), 0.7, 1.0, g, top_k=1).numel()) == 1
+    wide = torch.randn(4, 300, generator=g)
+    keep = wide.topk(5).indices
+    for _ in range(40):
+        pick = ref.sample_top_p(wide, 2.0, 1.0, g, top_k=5)
+        assert all(int(pick[b]) in keep[b].tolist() for b in range(4))

@@ -23,23 +23,7 @@ def drafter(dev):
     return EventChatModel.from_config(_cfg(1), torch.bfloat16, dev, seed=12)
 
 
-def _assert_lossless(v_eng, emb, got, want, tol=0.08):
-    """Speculative output == the verifier's own greedy output.  The verify pass scores several rows
-    with other kernels than the one-row decode step, so two candidates whose logits are closer
-    than bf16 rounding can swap; the first difference (if any) must be such a near-tie."""
-    n = min(len(got), len(want))
-    got, want = got[:n], want[:n]
-    if torch.equal(got, want):
-        return
-    i = int((got != want).nonzero()[0])
-    toks = want[:i].long()
-    ctx = torch.cat([emb, v_eng.embed[toks]]) if i else emb
-    v_eng.reset()
-    v_eng.prefill(ctx, select="logits")
-    row = v_eng.logits[0].float()
-    gap = abs(float(row[int(want[i])]) - float(row[int(got[i])]))
-    top2 = row.topk(2).indices.tolist()
-    assert gap < tol and int(want[i]) in top2 and int(got[i]) in top2, (i, gap, got.tolist(), want.tolist())
+from _lossless import assert_lossless as _assert_lossless  # noqa: E402
 
 
 def _emb(dev, n=40, seed=0):
@@ -189,6 +173,41 @@ def test_device_sampler_distribution(dev):
     out2 = torch.zeros(2, dtype=torch.int32, device=dev)
     hip.raw.sample_top_p(big, out2, 0.05, 1.0, 7, torch.zeros(2, dtype=torch.int32, device=dev))
     assert torch.equal(out2.long(), big.argmax(-1))
+
+
+def test_device_sampler_top_k(dev):
+    """top-k keeps exactly the k most likely tokens (all of a tie at the k-th value), then
+    top-p acts on what is left -- the order of temperature / top-k / top-p warpers."""
+    from eventgpt_amd.ops import hip
+    g = torch.Generator(device=dev).manual_seed(3)
+    V = 32003
+    logits = torch.randn(1, V, device=dev, generator=g)
+    out = torch.zeros(1, dtype=torch.int32, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    keep = set(logits[0].topk(7).indices.tolist())
+    seen = set()
+    for i in range(300):
+        step.fill_(i)
+        hip.raw.sample_top_p(logits, out, 3.0, 1.0, 5, step, 7)
+        seen.add(int(out[0]))
+    assert seen <= keep and len(seen) >= 5
+    # a tie at the k-th value keeps both tied tokens
+    tie = torch.full((1, 1003), -9.0, device=dev)
+    tie[0, [3, 10, 20, 30]] = torch.tensor([1.0, 0.5, 0.5, 0.0], device=dev)
+    seen = set()
+    for i in range(200):
+        step.fill_(i)
+        hip.raw.sample_top_p(tie, out, 1.0, 1.0, 11, step, 2)
+        seen.add(int(out[0]))
+    assert seen == {3, 10, 20}
+    # top-k 3 then top-p 0.5 of the renormalised three: only the mode survives
+    for i in range(50):
+        step.fill_(i)
+        hip.raw.sample_top_p(tie, out, 1.0, 0.4, 11, step, 3)
+        assert int(out[0]) == 3
+    # k = 1 is greedy
+    hip.raw.sample_top_p(logits, out, 1.0, 1.0, 1, step, 1)
+    assert int(out[0]) == int(logits.argmax())
 
 
 def test_linear_argmax_partials(dev):
