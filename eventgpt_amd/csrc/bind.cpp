@@ -764,6 +764,24 @@ std::tuple<Tensor, Tensor> event_voxel(const Tensor& x, const Tensor& y, const T
   return {hist, vox};
 }
 
+// Same outputs for a stream whose bins are index ranges: bounds int32 [bins+1] on the device,
+// non-decreasing, bounds[0] >= 0, bounds[bins] <= n (checked by the caller that built them).
+std::tuple<Tensor, Tensor> event_voxel_ranges(const Tensor& x, const Tensor& y, const Tensor& p,
+                                              const Tensor& bounds, int64_t H, int64_t W, bool signed_mode) {
+  check_i32(x, "x"); check_i32(y, "y"); check_i32(p, "p"); check_i32(bounds, "bounds");
+  const int64_t n = x.numel(), bins = bounds.numel() - 1;
+  TORCH_CHECK(y.numel() == n && p.numel() == n && bins >= 1 && H >= 1 && W >= 1);
+  TORCH_CHECK(evgpt::event_voxel_band_rows((int)H, (int)W) >= 1, "event_voxel_ranges: image too wide for an LDS band");
+  TORCH_CHECK(bins * 2 * H * W < (1ll << 31) && bins <= 65535);
+  Tensor hist = at::zeros({bins, 2, H, W}, x.options());
+  Tensor vox = at::zeros({bins, H, W}, x.options().dtype(at::kFloat));
+  if (n > 0)
+    evgpt::launch_event_voxel_ranges(x.data_ptr<int>(), y.data_ptr<int>(), p.data_ptr<int>(), bounds.data_ptr<int>(),
+                                     (int)n, (int)bins, (int)H, (int)W, hist.data_ptr<int>(), vox.data_ptr<float>(),
+                                     signed_mode ? 1 : 0, cur_stream());
+  return {hist, vox};
+}
+
 // img uint8 [T,H,W,3] -> bf16 [T,3,S,S]; tables are int32 GPU tensors
 Tensor clip_preprocess(const Tensor& img, const Tensor& hstart, const Tensor& hcount,
                        const Tensor& hweight, const Tensor& vstart, const Tensor& vcount,
@@ -950,6 +968,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("linear_argmax_partials(Tensor x, Tensor w, Tensor? bias) -> (Tensor, Tensor)", &linear_argmax_partials);
   m.def("event_raster(Tensor x, Tensor y, Tensor p, int n_slices, int H, int W, int mode) -> Tensor", &event_raster);
   m.def("event_voxel(Tensor x, Tensor y, Tensor p, Tensor t, int t0, int span, int bins, int H, int W, bool signed_mode, bool by_count) -> (Tensor, Tensor)", &event_voxel);
+  m.def("event_voxel_ranges(Tensor x, Tensor y, Tensor p, Tensor bounds, int H, int W, bool signed_mode) -> (Tensor, Tensor)", &event_voxel_ranges);
   m.def("clip_preprocess(Tensor img, Tensor hstart, Tensor hcount, Tensor hweight, Tensor vstart, Tensor vcount, Tensor vweight, int S, int resize_h, int resize_w, int top, int left, float[] mean, float[] stdv) -> Tensor", &clip_preprocess);
   m.def("gemm_force_config(int cfg) -> ()", &gemm_force_config);
   m.def("gemm_force_splitk(int sk) -> ()", &gemm_force_splitk);

@@ -13,6 +13,8 @@
 
 namespace evgpt {
 
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
 // keys: [T][H*W] int32, pre-filled with -1 (last) or 0 (negative-wins mask)
 __global__ __launch_bounds__(256) void raster_scatter_kernel(
     const int* __restrict__ x, const int* __restrict__ y, const int* __restrict__ p, int n_events,
@@ -90,6 +92,94 @@ void launch_event_voxel(const int* x, const int* y, const int* p, const long lon
   const double dspan = static_cast<double>(span > 0 ? span : 1);
   hipLaunchKernelGGL(voxel_kernel, dim3(blocks), dim3(256), 0, st, x, y, p, t, n_events, t0,
                      dspan, bins, H, W, out_hist, out_vox, signed_mode, by_count);
+}
+
+// LDS-privatised variant for event streams whose bins are index ranges (binning by count, or by
+// time on a time-sorted stream): bounds[b] .. bounds[b+1] are the events of bin b.  The
+// per-polarity count image of one bin (2 x H x W int32) does not fit the 160 KB of LDS, so it is
+// cut into bands of `rows` image rows; block (chunk, band, bin) scans its share of the bin's
+// events, reads only `y` for every event (4 B) and `x`, `p` for the ~rows/H that fall into its
+// band, counts them with LDS atomics, and flushes the non-zero counters: one global atomic per
+// touched pixel and block instead of one per event.  Reading y once per band costs H/rows x 4 B
+// per event, far less than an L2 atomic round trip per event.
+__global__ __launch_bounds__(256) void voxel_lds_kernel(
+    const int* __restrict__ x, const int* __restrict__ y, const int* __restrict__ p,
+    const int* __restrict__ bounds, int H, int W, int rows, int* __restrict__ out_hist,
+    float* __restrict__ out_vox, int signed_mode) {
+  extern __shared__ int cnt[];  // [2][rows][W]
+  const int b = blockIdx.z, y0 = blockIdx.y * rows;
+  const int band = min(rows, H - y0);
+  const int cells = 2 * rows * W;
+  for (int i = threadIdx.x; i < cells; i += 256) cnt[i] = 0;
+  __syncthreads();
+  const int lo = bounds[b], hi = bounds[b + 1];
+  // chunks of whole 1024-event groups: every block's loads are 16-byte aligned lane quads
+  const int first = lo & ~3;
+  const long long groups = (static_cast<long long>(hi) - first + 1023) / 1024;
+  const long long per = (groups + gridDim.x - 1) / gridDim.x;
+  const long long g0 = per * blockIdx.x, g1 = min(groups, g0 + per);
+  for (long long g = g0; g < g1; ++g) {
+    const int i0 = first + static_cast<int>(g) * 1024 + threadIdx.x * 4;
+    if (i0 >= hi) break;
+    int yv[4];
+    if (i0 + 3 < hi) {
+      const i32x4_t v = *reinterpret_cast<const i32x4_t*>(y + i0);
+      yv[0] = v[0]; yv[1] = v[1]; yv[2] = v[2]; yv[3] = v[3];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) yv[k] = i0 + k < hi ? y[i0 + k] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = yv[k] - y0, i = i0 + k;
+      if (i < lo || r < 0 || r >= band) continue;
+      const int xi = x[i];
+      if (xi < 0 || xi >= W) continue;
+      atomicAdd(&cnt[((p[i] != 0 ? rows : 0) + r) * W + xi], 1);
+    }
+  }
+  __syncthreads();
+  const int band_cells = band * W;
+  for (int i = threadIdx.x; i < band_cells; i += 256) {
+    const int neg = cnt[i], pos = cnt[rows * W + i];
+    if ((neg | pos) == 0) continue;
+    const size_t pix = static_cast<size_t>(y0) * W + i;
+    if (out_hist) {
+      if (neg) atomicAdd(out_hist + (static_cast<size_t>(b) * 2) * H * W + pix, neg);
+      if (pos) atomicAdd(out_hist + (static_cast<size_t>(b) * 2 + 1) * H * W + pix, pos);
+    }
+    if (out_vox)
+      atomicAdd(out_vox + static_cast<size_t>(b) * H * W + pix,
+                static_cast<float>(signed_mode ? pos - neg : pos + neg));
+  }
+}
+
+// rows of one band: as many as 150 KB of LDS hold for this width (0: image too wide)
+int event_voxel_band_rows(int H, int W) {
+  const int rows = (150 * 1024 / 4) / (2 * W);
+  return rows < H ? rows : H;
+}
+
+void launch_event_voxel_ranges(const int* x, const int* y, const int* p, const int* bounds, int n_events,
+                               int bins, int H, int W, int* out_hist, float* out_vox, int signed_mode,
+                               hipStream_t st) {
+  const int rows = event_voxel_band_rows(H, W);
+  const int bands = (H + rows - 1) / rows;
+  // ~3 blocks per CU in total, but no chunk below 64 K events (zeroing and flushing a band costs
+  // as much as scanning a few thousand events)
+  int chunks = (3 * 256 + bands * bins - 1) / (bands * bins);
+  const int by_size = n_events / bins / 65536;
+  if (chunks > by_size) chunks = by_size;
+  if (chunks < 1) chunks = 1;
+  const size_t smem = static_cast<size_t>(2) * rows * W * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&voxel_lds_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(voxel_lds_kernel, dim3(chunks, bands, bins), dim3(256), smem, st, x, y, p, bounds, H, W,
+                     rows, out_hist, out_vox, signed_mode);
 }
 
 // --------------------------------------------------------- CLIP preprocessing

@@ -19,7 +19,6 @@ from __future__ import annotations
 
 import io
 import os
-import pickle
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -31,28 +30,141 @@ _BLUE = np.array([0, 0, 255], dtype=np.uint8)
 
 
 # ----------------------------------------------------------------------- IO
-class _ArrayOnlyUnpickler(pickle.Unpickler):
-    """Unpickler that can only rebuild numpy arrays, dtypes and plain containers.
+class _Sym:
+    """Node of a pickle read *symbolically*: a named global, a call of one, or an object with state."""
 
-    Event samples in the wild are ``np.save``-d python dicts, i.e. pickles.  A
-    general unpickler runs arbitrary callables named by the file; this one
-    resolves exactly the four globals numpy needs to rebuild an ndarray and
-    refuses everything else.
-    """
+    __slots__ = ("kind", "a", "b")
 
-    _ALLOWED = {
-        ("numpy.core.multiarray", "_reconstruct"),
-        ("numpy._core.multiarray", "_reconstruct"),
-        ("numpy.core.multiarray", "scalar"),
-        ("numpy._core.multiarray", "scalar"),
-        ("numpy", "ndarray"),
-        ("numpy", "dtype"),
-    }
+    def __init__(self, kind, a=None, b=None):
+        self.kind, self.a, self.b = kind, a, b
 
-    def find_class(self, module, name):
-        if (module, name) in self._ALLOWED:
-            return super().find_class(module, name)
-        raise pickle.UnpicklingError(f"refusing to load global {module}.{name}")
+
+_MARK = object()
+
+
+def _read_pickle_symbolic(f):
+    """Walk a pickle stream opcode by opcode WITHOUT executing it: globals stay names, ``REDUCE`` and
+    ``BUILD`` only record (callable name, arguments, state).  Nothing is imported, called or
+    constructed, so a hostile file can at most produce a tree this module then refuses.  Only the
+    opcodes numpy's array pickles use are understood; any other opcode raises ``ValueError``.
+
+    Event samples in the wild are ``np.save``-d python dicts (reference: common/common.py:111-112),
+    i.e. pickles; this is how they are read when the file is not trusted."""
+    import pickletools
+    stack, memo = [], {}
+
+    def pop_mark():
+        k = len(stack) - 1
+        while stack[k] is not _MARK:
+            k -= 1
+        items = stack[k + 1:]
+        del stack[k:]
+        return items
+
+    for op, arg, _pos in pickletools.genops(f):
+        n = op.name
+        if n in ("PROTO", "FRAME"):
+            pass
+        elif n == "GLOBAL":
+            mod, name = arg.split(" ")
+            stack.append(_Sym("global", mod, name))
+        elif n == "STACK_GLOBAL":
+            name, mod = stack.pop(), stack.pop()
+            stack.append(_Sym("global", mod, name))
+        elif n in ("BINPUT", "LONG_BINPUT", "PUT"):
+            memo[int(arg)] = stack[-1]
+        elif n == "MEMOIZE":
+            memo[len(memo)] = stack[-1]
+        elif n in ("BINGET", "LONG_BINGET", "GET"):
+            stack.append(memo[int(arg)])
+        elif n in ("BININT", "BININT1", "BININT2", "LONG1", "LONG4", "INT", "LONG", "BINFLOAT",
+                   "BINUNICODE", "SHORT_BINUNICODE", "BINUNICODE8", "BINBYTES", "SHORT_BINBYTES", "BINBYTES8",
+                   "BINSTRING", "SHORT_BINSTRING"):
+            stack.append(arg)
+        elif n == "NONE":
+            stack.append(None)
+        elif n == "NEWTRUE":
+            stack.append(True)
+        elif n == "NEWFALSE":
+            stack.append(False)
+        elif n == "MARK":
+            stack.append(_MARK)
+        elif n == "EMPTY_TUPLE":
+            stack.append(())
+        elif n in ("TUPLE1", "TUPLE2", "TUPLE3"):
+            k = int(n[-1])
+            items = tuple(stack[-k:])
+            del stack[-k:]
+            stack.append(items)
+        elif n == "TUPLE":
+            stack.append(tuple(pop_mark()))
+        elif n == "EMPTY_LIST":
+            stack.append([])
+        elif n == "EMPTY_DICT":
+            stack.append({})
+        elif n == "APPEND":
+            v = stack.pop()
+            stack[-1].append(v)
+        elif n == "APPENDS":
+            items = pop_mark()
+            stack[-1].extend(items)
+        elif n == "SETITEM":
+            v, k = stack.pop(), stack.pop()
+            stack[-1][k] = v
+        elif n == "SETITEMS":
+            items = pop_mark()
+            for k, v in zip(items[::2], items[1::2]):
+                stack[-1][k] = v
+        elif n == "REDUCE":
+            args, fn = stack.pop(), stack.pop()
+            stack.append(_Sym("call", fn, args))
+        elif n == "BUILD":
+            state, obj = stack.pop(), stack.pop()
+            stack.append(_Sym("built", obj, state))
+        elif n == "STOP":
+            return stack.pop()
+        else:
+            raise ValueError(f"pickle opcode {n} is not part of an array container")
+    raise ValueError("pickle stream ended without STOP")
+
+
+def _is_global(node, names) -> bool:
+    return isinstance(node, _Sym) and node.kind == "global" and (node.a, node.b) in names
+
+
+def _array_from_symbolic(node) -> np.ndarray:
+    """``ndarray.__reduce__`` as numpy writes it: ``_reconstruct(ndarray, (0,), b'b')`` built with
+    ``(version, shape, dtype, is_fortran, raw bytes | list for object arrays)``."""
+    recon = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct")}
+    if not (isinstance(node, _Sym) and node.kind == "built" and isinstance(node.a, _Sym) and node.a.kind == "call"
+            and _is_global(node.a.a, recon) and _is_global(node.a.b[0], {("numpy", "ndarray")})):
+        raise ValueError("not a pickled ndarray")
+    _version, shape, dt, fortran, raw = node.b
+    dnode = dt.a if dt.kind == "built" else dt
+    if not (dnode.kind == "call" and _is_global(dnode.a, {("numpy", "dtype")}) and isinstance(dnode.b[0], str)):
+        raise ValueError("unsupported dtype record")
+    code = dnode.b[0]
+    if code.startswith("O"):
+        return raw                        # object array: its element list (the dict of a 0-d np.save)
+    if not (len(code) in (2, 3) and code[-2] in "uifb" and code[-1] in "1248") or fortran:
+        raise ValueError(f"unsupported array dtype {code!r}")
+    order = dt.b[1] if dt.kind == "built" and dt.b[1] in ("<", ">", "|", "=") else "="
+    if isinstance(raw, str):              # protocol-2 pickles carry bytes as latin-1 text
+        raw = raw.encode("latin1")
+    arr = np.frombuffer(raw, dtype=np.dtype(code).newbyteorder(order))
+    if not all(isinstance(d, int) and d >= 0 for d in shape) or int(np.prod(shape, dtype=np.int64)) != arr.size:
+        raise ValueError("array payload does not match its shape")
+    return arr.reshape(shape).astype(arr.dtype.newbyteorder("="), copy=True)
+
+
+def read_pickled_event_dict(f) -> dict:
+    """The ``{x, y, t, p}`` dict of a pickled 0-d object array, read without unpickling anything."""
+    top = _array_from_symbolic(_read_pickle_symbolic(f))
+    if isinstance(top, list) and len(top) == 1:
+        top = top[0]
+    if not isinstance(top, dict):
+        raise ValueError("pickled container does not hold a dict")
+    return {k: _array_from_symbolic(v) for k, v in top.items() if isinstance(k, str)}
 
 
 def _validate(ev: dict) -> EventDict:
@@ -71,9 +183,9 @@ def load_event_npy(path: str, trusted: bool = False) -> EventDict:
 
     Accepted containers: ``.npz`` with arrays ``x,y,t,p``; a structured ``.npy``
     with those fields; or the pickled-dict ``.npy`` used by EventGPT samples
-    (reference: common/common.py:111-112).  Pickled files go through
-    ``_ArrayOnlyUnpickler`` unless ``trusted`` (then plain ``np.load`` with
-    ``allow_pickle``).
+    (reference: common/common.py:111-112).  Pickled files are read symbolically
+    (``read_pickled_event_dict``: no opcode of the file is executed) unless ``trusted``
+    (then plain ``np.load`` with ``allow_pickle``).
     """
     if path.endswith(".npz"):
         with np.load(path) as z:
@@ -89,10 +201,7 @@ def load_event_npy(path: str, trusted: bool = False) -> EventDict:
                 np.lib.format.read_array_header_1_0(f)
             else:
                 np.lib.format.read_array_header_2_0(f)
-            obj = _ArrayOnlyUnpickler(f).load()
-        if isinstance(obj, np.ndarray) and obj.dtype == object:
-            obj = obj.item()
-        return _validate(obj)
+            return _validate(read_pickled_event_dict(f))
     if arr.dtype.names:
         return _validate({k: arr[k] for k in arr.dtype.names})
     raise ValueError(f"{path}: not an event container")

@@ -6,7 +6,7 @@ with three launches on device-resident event arrays:
 
     event_raster    one atomic per event (last-wins / negative-wins), all T slices
     clip_preprocess PIL-exact two-pass bicubic + crop + normalise, all T frames
-    (event_voxel    time-binned polarity histogram / signed voxel grid)
+    (event_voxel    time-binned polarity histogram / signed voxel grid; LDS-privatised per band)
 
 The resample tables are the ones ``data.clip_preprocess`` builds, so device and
 host produce bit-identical uint8 images.
@@ -46,15 +46,44 @@ def rasterize_gpu(ev: Dict[str, torch.Tensor], n_slices: int = 5,
     return hip.raw.event_raster(ev["x"], ev["y"], ev["p"], n_slices, size[0], size[1], mode)
 
 
+def _bin_bounds(ev: Dict[str, torch.Tensor], bins: int, by: str, t0: int, span: int) -> Optional[torch.Tensor]:
+    """Device int32 ``[bins+1]``: events ``bounds[b]:bounds[b+1]`` form bin ``b`` -- or ``None``
+    when binning by time on a stream that is not time-sorted (bins are then no index ranges)."""
+    n = ev["t"].numel()
+    dev = ev["t"].device
+    if by == "count":
+        # event i goes to bin floor(i * bins / n): bin b starts at ceil(b * n / bins)
+        b = torch.arange(bins + 1, dtype=torch.int64)
+        return ((b * n + bins - 1) // bins).to(torch.int32).to(dev)
+    t = ev["t"]
+    if n > 1 and not bool((t[1:] >= t[:-1]).all()):
+        return None
+    # the kernel's own arithmetic (double): bin = clamp(int((t - t0) / span * bins))
+    which = ((t - t0).to(torch.float64) / float(span) * bins).to(torch.int64).clamp_(0, bins - 1)
+    edges = torch.arange(bins + 1, dtype=torch.int64, device=dev)
+    return torch.searchsorted(which, edges).to(torch.int32)
+
+
 def voxel_grid_gpu(ev: Dict[str, torch.Tensor], bins: int = 5,
                    size: Optional[Tuple[int, int]] = None, signed: bool = True,
-                   by: str = "time") -> Tuple[torch.Tensor, torch.Tensor]:
-    """``(hist int32 [bins,2,H,W], voxel fp32 [bins,H,W])``."""
+                   by: str = "time", privatised: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(hist int32 [bins,2,H,W], voxel fp32 [bins,H,W])``.
+
+    Two kernels produce the same numbers: one global atomic per event, and (``privatised``,
+    the default whenever the bins are index ranges: binning by count, or by time on a sorted
+    stream) per-band counting in LDS with one global atomic per touched pixel."""
     from . import hip
     if size is None:
         size = (int(ev["y"].max()) + 1, int(ev["x"].max()) + 1)
     t0 = int(ev["t"].min()) if ev["t"].numel() else 0
     span = max(int(ev["t"].max()) - t0, 1) if ev["t"].numel() else 1
+    if privatised is None:
+        privatised = ev["t"].numel() >= 4096
+    if privatised:
+        bounds = _bin_bounds(ev, bins, by, t0, span)
+        if bounds is not None:
+            x, y, p = (a if a.data_ptr() % 16 == 0 else a.clone() for a in (ev["x"], ev["y"], ev["p"]))
+            return hip.raw.event_voxel_ranges(x, y, p, bounds, size[0], size[1], signed)
     return hip.raw.event_voxel(ev["x"], ev["y"], ev["p"], ev["t"], t0, span, bins, size[0],
                                size[1], signed, by == "count")
 

@@ -596,6 +596,25 @@ class GenerationEngine:
         return self.generate_continue(budget, None, temperature, top_p, generator, top_k)
 
     @torch.no_grad()
+    def score(self, embeds: torch.Tensor, tokens: torch.Tensor) -> torch.Tensor:
+        """Teacher-forced logits of sequence 0: row 0 predicts the token after the prompt, row
+        ``i`` the token after ``tokens[i-1]`` -- ``[len(tokens)+1, V]`` fp32.  The given tokens
+        are committed instead of the model's own choice (one decode step each), so two
+        implementations can be compared on logits along the SAME path rather than on how
+        long their greedy outputs happen to agree."""
+        eos, self.eos = self.eos, -1
+        self.reset()
+        self.prefill(embeds, select="logits")
+        rows = [self.logits[0].float().clone()]
+        for t in tokens.tolist():
+            self.sampled[0] = int(t)
+            self._commit_sampled()
+            self.decode_step(greedy=False)
+            rows.append(self.logits[0].float().clone())
+        self.eos = eos
+        return torch.stack(rows)
+
+    @torch.no_grad()
     def generate_continue(self, max_new_tokens: int, eos_token_id: Optional[int] = None,
                           temperature: float = 0.0, top_p: float = 1.0,
                           generator: Optional[torch.Generator] = None, top_k: int = 0) -> torch.Tensor:

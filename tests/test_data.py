@@ -1,3 +1,5 @@
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -107,7 +109,7 @@ def test_event_npy_roundtrip_safe_loader(tmp_path):
     ev = synthetic_events(1000, 64, 48)
     p = str(tmp_path / "s.npy")
     save_event_npy(p, ev)                      # pickled dict, the sample-file format
-    back = load_event_npy(p)                   # array-only unpickler
+    back = load_event_npy(p)                   # symbolic reader: nothing in the file is executed
     for k in "xytp":
         assert np.array_equal(back[k], ev[k]) and back[k].dtype == ev[k].dtype
     pz = str(tmp_path / "s.npz")
@@ -115,15 +117,25 @@ def test_event_npy_roundtrip_safe_loader(tmp_path):
     assert np.array_equal(load_event_npy(pz)["t"], ev["t"])
 
 
-def test_safe_loader_refuses_arbitrary_globals(tmp_path):
-    import pickle
+def test_safe_loader_never_executes_the_file(tmp_path, capsys):
+    """A pickle that would call a function on load is read as a tree of names and refused:
+    the callable is never looked up, let alone run."""
+    ran = []
 
     class Evil:
         def __reduce__(self):
-            return (print, ("pwned",))
+            return (ran.append, ("pwned",))
     p = str(tmp_path / "evil.npy")
     np.save(p, np.array({"x": Evil()}, dtype=object), allow_pickle=True)
-    with pytest.raises(pickle.UnpicklingError):
+    with pytest.raises((ValueError, KeyError)):
+        load_event_npy(p)
+    assert ran == []
+
+    class Sneaky:                       # a global outside numpy's array protocol in place of an array
+        def __reduce__(self):
+            return (os.getcwd, ())
+    np.save(p, np.array({k: Sneaky() for k in "xytp"}, dtype=object), allow_pickle=True)
+    with pytest.raises(ValueError):
         load_event_npy(p)
 
 

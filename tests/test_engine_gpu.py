@@ -50,23 +50,72 @@ def test_greedy_graph_equals_eager_and_module(model, dev):
     t_graph = eng.generate(emb, N, eos_token_id=-1)
     t_graph2 = eng.generate(emb, N, eos_token_id=-1)   # replay after other eager work
     assert torch.equal(t_eager, t_graph) and torch.equal(t_graph, t_graph2)
-    t_mod = model.generate_from_embeds(emb[None], max_new_tokens=N, use_engine=False,
-                                       eos_token_id=-1)[0]
-    # bf16 paths differ in rounding order; demand a long common prefix, not identity
-    same = (t_mod[:len(t_graph)] == t_graph).long().cumprod(0).sum().item()
-    assert same >= 4, (t_mod, t_graph)
+    # against the module path: logits along the SAME (teacher-forced) token path; the two
+    # bf16 implementations differ only in rounding order
+    got = eng.score(emb, t_graph[:-1])
+    want = _module_logits(model, emb, t_graph[:-1])
+    _assert_logits_close(got, want)
+    # and the engine's greedy choice is the module's argmax wherever that argmax is not a near-tie
+    top2 = want.topk(2).values
+    clear = (top2[:, 0] - top2[:, 1]) > 0.1
+    assert int(clear.sum()) >= N // 2
+    assert torch.equal(want.argmax(-1)[clear], t_graph[clear])
 
 
-def test_greedy_matches_cpu_fp32_prefix(model, dev):
+def _module_logits(m, emb, tokens):
+    """Teacher-forced logits of the nn.Module path (any device / dtype): one forward over prompt + tokens."""
+    e = m.get_model().embed_tokens
+    seq = torch.cat([emb.to(e.weight), e(tokens.to(e.weight.device))])[None]
+    with torch.no_grad():
+        out = m(inputs_embeds=seq)
+    return out.logits[0, emb.shape[0] - 1:].float()
+
+
+def _assert_logits_close(got, want, cos_min=0.999, rel_max=0.03):
+    """Row-wise cosine and max-abs error relative to the row's own spread (max - mean)."""
+    got, want = got.float().cpu(), want.float().cpu()
+    assert got.shape == want.shape
+    cos = torch.nn.functional.cosine_similarity(got, want, dim=-1)
+    spread = (want.max(-1).values - want.mean(-1)).clamp_min(1e-6)
+    rel = (got - want).abs().max(-1).values / spread
+    assert float(cos.min()) > cos_min and float(rel.max()) < rel_max, (float(cos.min()), float(rel.max()))
+
+
+def test_teacher_forced_logits_match_cpu_fp32(model, dev):
     S, N = 30, 8
     emb = (torch.randn(S, 512, device=dev) * 0.5).to(torch.bfloat16)
     eng = model.engine(max_len=512, max_new_tokens=64)
     t = eng.generate(emb, N, eos_token_id=-1)
-    import copy
     cpu = EventChatModel.from_config(_small_cfg(), torch.float32, "cpu", seed=None)
     cpu.load_state_dict({k: v.float().cpu() for k, v in model.state_dict().items()})
-    t_cpu = cpu.generate_from_embeds(emb[None].float().cpu(), max_new_tokens=N, eos_token_id=-1)[0]
-    assert t[0].item() == t_cpu[0].item(), (t, t_cpu)
+    want = _module_logits(cpu, emb.float().cpu(), t[:-1].cpu())
+    _assert_logits_close(eng.score(emb, t[:-1]), want)
+    assert int(t[0]) in want[0].topk(2).indices.tolist()
+
+
+@pytest.mark.timeout(600)
+def test_7b_geometry_two_layers_logits(dev):
+    """EventGPT-7B layer geometry (4096 / 11008 / 32 heads of 128 / vocab 32000), two layers: the
+    shapes the production kernels are tuned for (GEMV K-split, 128-wide attention, lm_head argmax
+    partials), which the 512-wide test models never reach.  Engine (graph replay) vs module path
+    (bf16) vs CPU fp32, teacher-forced along the engine's own greedy path, at a 636-token prompt."""
+    cfg = EventChatConfig(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=2,
+                          num_attention_heads=32, max_position_embeddings=4096, torch_dtype="bfloat16")
+    m = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=5)
+    g = torch.Generator(device=dev).manual_seed(1)
+    emb = (torch.randn(636, 4096, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    eng = m.engine(max_len=1024, max_new_tokens=32)
+    toks = eng.generate(emb, 12, eos_token_id=-1)
+    assert eng.graph_captured
+    got = eng.score(emb, toks[:-1])
+    assert torch.equal(got.argmax(-1), toks)                      # score() retraces generate()
+    want_mod = _module_logits(m, emb, toks[:-1])
+    _assert_logits_close(got, want_mod)
+    cpu = EventChatModel.from_config(cfg, torch.float32, "cpu", seed=None)
+    cpu.load_state_dict({k: v.float().cpu() for k, v in m.state_dict().items()})
+    want_cpu = _module_logits(cpu, emb.float().cpu(), toks[:-1].cpu())
+    _assert_logits_close(got, want_cpu)
+    _assert_logits_close(want_mod, want_cpu)                      # the oracle pair itself, same bound
 
 
 def test_eos_stops(model, dev):
@@ -126,10 +175,10 @@ def test_batched_engine_matches_single_stream(model, dev, B):
     eng.prefill_batch(prompts)
     for _ in range(9):
         eng.decode_step(True)
+    from _lossless import assert_lossless
     for b in range(B):
-        got = eng.tokens(b)
-        same = (got == want[b]).long().cumprod(0).sum().item()
-        assert same >= 6, (b, got.tolist(), want[b].tolist())
+        # identical, or first differing at two candidates the single-stream logits cannot tell apart
+        assert_lossless(single, prompts[b], eng.tokens(b).long(), want[b])
 
 
 @pytest.mark.timeout(300)
@@ -182,18 +231,15 @@ def test_continuous_batching_matches_single_stream(model, dev):
     eng = TensorParallelEngine(model, None, max_len=256, max_batch=3, max_new_tokens=32)
     cb = ContinuousBatcher(eng, eos_token_id=-1, poll_every=4, max_admit_per_step=2)
     done_order = []
+    from _lossless import assert_lossless
     reqs = [cb.submit(p, b, on_finish=lambda r: done_order.append(r.rid)) for p, b in zip(prompts, budgets)]
     fin = cb.run_until_idle(max_steps=500)
     assert cb.idle and len(fin) == 7 and sorted(done_order) == list(range(7))
     assert sorted(cb.free) == [0, 1, 2] and int(eng.active.sum()) == 0
     for r, w, b in zip(reqs, want, budgets):
         assert r.finished and len(r.tokens) == b
-        same = 0
-        for x, y in zip(r.tokens, w):
-            if x != y:
-                break
-            same += 1
-        assert same >= min(b, 5), (r.rid, r.tokens, w)     # identical up to batched-kernel rounding
+        # identical up to batched-kernel rounding: a first difference must be a logit near-tie
+        assert_lossless(single, prompts[r.rid], torch.tensor(r.tokens, device=dev), torch.tensor(w, device=dev))
     st = cb.stats()
     assert st["requests"] == 7 and st["tokens"] == sum(budgets) and st["decode_steps"] < sum(budgets)
     # EOS ends a request early: pick a token the model is known to emit

@@ -32,6 +32,39 @@ def test_voxel_and_histogram_match_numpy(dev):
     assert np.allclose(voxc.cpu().numpy(), voxel_grid(ev, 5, (48, 64), signed=False, by="count"))
 
 
+@pytest.mark.parametrize("n,hw,bins", [(200_000, (480, 640), 5), (70_001, (97, 130), 3), (5000, (48, 64), 7)])
+@pytest.mark.parametrize("by", ["time", "count"])
+def test_voxel_lds_bands_equal_atomic_kernel_and_numpy(dev, n, hw, bins, by):
+    """The per-band LDS histogram and the one-atomic-per-event kernel give identical counts;
+    both match the host implementation, with out-of-canvas events dropped."""
+    from eventgpt_amd.ops import event_ops as eo
+    ev = synthetic_events(n, hw[1] + 6, hw[0] + 4, seed=n % 97)      # some events fall outside the canvas
+    d = eo.events_to_device(ev, dev)
+    h_lds, v_lds = eo.voxel_grid_gpu(d, bins, hw, by=by, privatised=True)
+    h_at, v_at = eo.voxel_grid_gpu(d, bins, hw, by=by, privatised=False)
+    assert torch.equal(h_lds, h_at) and torch.equal(v_lds, v_at)
+    inside = (ev["x"] < hw[1]) & (ev["y"] < hw[0])
+    assert int(h_lds.sum()) == int(inside.sum())
+    if by == "time":
+        keep = {k: v[inside] for k, v in ev.items()}
+        t0, t1 = int(ev["t"].min()), int(ev["t"].max())
+        b = np.clip(((keep["t"] - t0).astype(np.float64) / max(t1 - t0, 1) * bins).astype(np.int64), 0, bins - 1)
+        want = np.zeros((bins, 2) + hw, np.int64)
+        np.add.at(want, (b, (keep["p"] != 0).astype(np.int64), keep["y"], keep["x"]), 1)
+        assert np.array_equal(h_lds.cpu().numpy(), want)
+
+
+def test_voxel_unsorted_stream_takes_the_atomic_kernel(dev):
+    from eventgpt_amd.ops import event_ops as eo
+    ev = synthetic_events(20_000, 64, 48, seed=5)
+    perm = np.random.default_rng(0).permutation(20_000)
+    shuffled = {k: v[perm] for k, v in ev.items()}
+    d = eo.events_to_device(shuffled, dev)
+    assert eo._bin_bounds(d, 5, "time", int(ev["t"].min()), int(ev["t"].max() - ev["t"].min())) is None
+    hist, _ = eo.voxel_grid_gpu(d, 5, (48, 64), privatised=True)
+    assert np.array_equal(hist.cpu().numpy(), polarity_histogram(ev, 5, (48, 64)))
+
+
 @pytest.mark.parametrize("hw", [(480, 640), (120, 160), (336, 336), (400, 300)])
 def test_clip_preprocess_matches_host(dev, hw):
     from eventgpt_amd.ops import event_ops as eo
