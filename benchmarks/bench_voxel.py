@@ -13,11 +13,16 @@ def main():
     n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
-    ev = {"x": torch.randint(0, 640, (n,), device=dev, generator=g, dtype=torch.int32),
-          "y": torch.randint(0, 480, (n,), device=dev, generator=g, dtype=torch.int32),
-          "p": torch.randint(0, 2, (n,), device=dev, generator=g, dtype=torch.int32),
-          "t": torch.sort(torch.randint(0, 50_000, (n,), device=dev, generator=g, dtype=torch.int64)).values}
-    for by in ("count", "time"):
+    t = torch.sort(torch.randint(0, 50_000, (n,), device=dev, generator=g, dtype=torch.int64)).values
+    p = torch.randint(0, 2, (n,), device=dev, generator=g, dtype=torch.int32)
+    uniform = {"x": torch.randint(0, 640, (n,), device=dev, generator=g, dtype=torch.int32),
+               "y": torch.randint(0, 480, (n,), device=dev, generator=g, dtype=torch.int32), "p": p, "t": t}
+    # a scene: events cluster on a few moving edges (8 blobs, sigma 12 px), as sensor data does
+    c = torch.rand(8, 2, device=dev, generator=g) * torch.tensor([640.0, 480.0], device=dev)
+    which = torch.randint(0, 8, (n,), device=dev, generator=g)
+    pos = c[which] + torch.randn(n, 2, device=dev, generator=g) * 12.0
+    scene = {"x": pos[:, 0].clamp(0, 639).to(torch.int32), "y": pos[:, 1].clamp(0, 479).to(torch.int32), "p": p, "t": t}
+    for name, ev, by in (("uniform", uniform, "count"), ("uniform", uniform, "time"), ("clustered", scene, "time")):
         res = {}
         for priv in (False, True):
             for _ in range(2):
@@ -29,7 +34,7 @@ def main():
             torch.cuda.synchronize()
             res[priv] = ((time.perf_counter() - t0) / 10 * 1e3, out)
         assert torch.equal(res[False][1][0], res[True][1][0])
-        print(f"{n:.0e} events, by {by}: atomic-per-event {res[False][0]:.3f} ms, LDS bands {res[True][0]:.3f} ms "
+        print(f"{n:.0e} {name} events, by {by}: atomic-per-event {res[False][0]:.3f} ms, LDS bands {res[True][0]:.3f} ms "
               f"({n / res[True][0] / 1e6:.1f} G events/s), whole call incl. bounds + output zeroing", flush=True)
 
 

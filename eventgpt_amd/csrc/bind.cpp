@@ -468,7 +468,7 @@ Tensor swiglu_bwd(const Tensor& gate_up, const Tensor& gh) {
 // master weights and moments, all of the same length; updates master, moments and param_out.
 void fused_adamw(const Tensor& grad, const Tensor& master, const Tensor& exp_avg, const Tensor& exp_avg_sq,
                  const Tensor& param_out, double lr, double beta1, double beta2, double eps,
-                 double weight_decay, int64_t step, double clip) {
+                 double weight_decay, int64_t step, double clip, const c10::optional<Tensor>& clip_dev) {
   check_f32(master, "master"); check_f32(exp_avg, "exp_avg"); check_f32(exp_avg_sq, "exp_avg_sq");
   const int64_t n = master.numel();
   TORCH_CHECK(grad.is_cuda() && grad.is_contiguous() && param_out.is_cuda() && param_out.is_contiguous() &&
@@ -476,6 +476,12 @@ void fused_adamw(const Tensor& grad, const Tensor& master, const Tensor& exp_avg
               "fused_adamw: all tensors are contiguous device tensors of one length");
   TORCH_CHECK(grad.scalar_type() == param_out.scalar_type() && step >= 1, "fused_adamw: dtype/step");
   evgpt::AdamWArgs a;
+  a.clip_dev = nullptr;
+  if (clip_dev.has_value()) {
+    check_f32(*clip_dev, "clip_dev");
+    TORCH_CHECK(clip_dev->numel() == 1, "fused_adamw: clip_dev is one device scalar");
+    a.clip_dev = clip_dev->data_ptr<float>();
+  }
   a.clip = (float)clip; a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps;
   a.decay = (float)(1.0 - lr * weight_decay);
   a.step_size = (float)(lr / (1.0 - std::pow(beta1, (double)step)));
@@ -954,7 +960,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("decode_gemv_residual(Tensor w, Tensor xin, Tensor(a!) y) -> ()", &decode_gemv_residual);
   m.def("rmsnorm_bwd(Tensor x, Tensor weight, Tensor grad, float eps, bool want_dw=False) -> (Tensor, Tensor)", &rmsnorm_bwd);
   m.def("swiglu_bwd(Tensor gate_up, Tensor grad) -> Tensor", &swiglu_bwd);
-  m.def("fused_adamw(Tensor grad, Tensor(a!) master, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor(d!) param_out, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float clip) -> ()", &fused_adamw);
+  m.def("fused_adamw(Tensor grad, Tensor(a!) master, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor(d!) param_out, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float clip, Tensor? clip_dev=None) -> ()", &fused_adamw);
   m.def("w4_dequant(Tensor packed, Tensor absmax, Tensor code, Tensor(a!)? out=None) -> Tensor", &w4_dequant);
   m.def("gemv_w4_max_batch() -> int", []() { return (int64_t)evgpt::gemv_w4_max_batch(); });
   m.def("decode_qkv_w4(Tensor x, Tensor norm_w, Tensor packed, Tensor absmax, Tensor code, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos, float eps, int Hq, int Hkv, int D, bool one_seq=False) -> ()", &decode_qkv_w4);

@@ -41,7 +41,12 @@ void launch_rmsnorm_bwd(const bf16_t* x, const bf16_t* w, const bf16_t* g, bf16_
 void launch_swiglu_bwd(const bf16_t* gate_up, const bf16_t* gh, bf16_t* dgu, long long M, int I, hipStream_t st);
 
 // ---- optim.hip
-struct AdamWArgs { float clip, beta1, beta2, eps, decay /* 1 - lr*wd */, step_size /* lr / bc1 */, inv_sqrt_bc2; };
+// clip_dev (optional): a device scalar multiplied into `clip` by the kernel itself, so a clip factor
+// derived from the global gradient norm never has to visit the host
+struct AdamWArgs {
+  float clip, beta1, beta2, eps, decay /* 1 - lr*wd */, step_size /* lr / bc1 */, inv_sqrt_bc2;
+  const float* clip_dev;
+};
 void launch_fused_adamw_bf16(const bf16_t* grad, float* master, float* m, float* v, bf16_t* out, long long n,
                              const AdamWArgs& a, hipStream_t st);
 void launch_fused_adamw_f32(const float* grad, float* master, float* m, float* v, float* out, long long n,

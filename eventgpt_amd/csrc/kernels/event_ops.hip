@@ -102,7 +102,10 @@ void launch_event_voxel(const int* x, const int* y, const int* p, const long lon
 // band, counts them with LDS atomics, and flushes the non-zero counters: one global atomic per
 // touched pixel and block instead of one per event.  Reading y once per band costs H/rows x 4 B
 // per event, far less than an L2 atomic round trip per event.
-__global__ __launch_bounds__(256) void voxel_lds_kernel(
+constexpr int VL_THREADS = 1024;  // one block per CU (the band fills LDS): 16 waves hide the load latency
+constexpr int VL_DEPTH = 4;       // y vectors in flight per thread
+
+__global__ __launch_bounds__(VL_THREADS) void voxel_lds_kernel(
     const int* __restrict__ x, const int* __restrict__ y, const int* __restrict__ p,
     const int* __restrict__ bounds, int H, int W, int rows, int* __restrict__ out_hist,
     float* __restrict__ out_vox, int signed_mode) {
@@ -110,37 +113,44 @@ __global__ __launch_bounds__(256) void voxel_lds_kernel(
   const int b = blockIdx.z, y0 = blockIdx.y * rows;
   const int band = min(rows, H - y0);
   const int cells = 2 * rows * W;
-  for (int i = threadIdx.x; i < cells; i += 256) cnt[i] = 0;
+  for (int i = threadIdx.x; i < cells; i += VL_THREADS) cnt[i] = 0;
   __syncthreads();
   const int lo = bounds[b], hi = bounds[b + 1];
-  // chunks of whole 1024-event groups: every block's loads are 16-byte aligned lane quads
+  // chunks of whole groups of 4 * VL_THREADS events: every load is a 16-byte aligned lane quad
+  constexpr int GROUP = 4 * VL_THREADS;
   const int first = lo & ~3;
-  const long long groups = (static_cast<long long>(hi) - first + 1023) / 1024;
+  const long long groups = (static_cast<long long>(hi) - first + GROUP - 1) / GROUP;
   const long long per = (groups + gridDim.x - 1) / gridDim.x;
   const long long g0 = per * blockIdx.x, g1 = min(groups, g0 + per);
-  for (long long g = g0; g < g1; ++g) {
-    const int i0 = first + static_cast<int>(g) * 1024 + threadIdx.x * 4;
-    if (i0 >= hi) break;
-    int yv[4];
-    if (i0 + 3 < hi) {
-      const i32x4_t v = *reinterpret_cast<const i32x4_t*>(y + i0);
-      yv[0] = v[0]; yv[1] = v[1]; yv[2] = v[2]; yv[3] = v[3];
-    } else {
+  for (long long g = g0; g < g1; g += VL_DEPTH) {
+    i32x4_t yv[VL_DEPTH];
+    int base[VL_DEPTH];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) yv[k] = i0 + k < hi ? y[i0 + k] : -1;
+    for (int d = 0; d < VL_DEPTH; ++d) {      // all y loads of this round first
+      base[d] = first + static_cast<int>(g + d) * GROUP + threadIdx.x * 4;
+      const bool in = g + d < g1 && base[d] < hi;
+      if (in && base[d] + 3 < hi) {
+        yv[d] = *reinterpret_cast<const i32x4_t*>(y + base[d]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) yv[d][k] = (in && base[d] + k < hi) ? y[base[d] + k] : -1;
+      }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int r = yv[k] - y0, i = i0 + k;
-      if (i < lo || r < 0 || r >= band) continue;
-      const int xi = x[i];
-      if (xi < 0 || xi >= W) continue;
-      atomicAdd(&cnt[((p[i] != 0 ? rows : 0) + r) * W + xi], 1);
+    for (int d = 0; d < VL_DEPTH; ++d) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = yv[d][k] - y0, i = base[d] + k;
+        if (i < lo || r < 0 || r >= band) continue;
+        const int xi = x[i];
+        if (xi < 0 || xi >= W) continue;
+        atomicAdd(&cnt[((p[i] != 0 ? rows : 0) + r) * W + xi], 1);
+      }
     }
   }
   __syncthreads();
   const int band_cells = band * W;
-  for (int i = threadIdx.x; i < band_cells; i += 256) {
+  for (int i = threadIdx.x; i < band_cells; i += VL_THREADS) {
     const int neg = cnt[i], pos = cnt[rows * W + i];
     if ((neg | pos) == 0) continue;
     const size_t pix = static_cast<size_t>(y0) * W + i;
@@ -178,7 +188,7 @@ void launch_event_voxel_ranges(const int* x, const int* y, const int* p, const i
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(voxel_lds_kernel, dim3(chunks, bands, bins), dim3(256), smem, st, x, y, p, bounds, H, W,
+  hipLaunchKernelGGL(voxel_lds_kernel, dim3(chunks, bands, bins), dim3(VL_THREADS), smem, st, x, y, p, bounds, H, W,
                      rows, out_hist, out_vox, signed_mode);
 }
 

@@ -29,6 +29,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void fused_adamw_kernel(const T* __restrict__ grad, float* __restrict__ master,
                                                           float* __restrict__ m, float* __restrict__ v,
                                                           T* __restrict__ param_out, long long n, AdamWArgs a) {
+  if (a.clip_dev) a.clip *= *a.clip_dev;
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x * 4;
   for (long long i0 = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i0 < n; i0 += stride) {
 #pragma unroll
@@ -48,6 +49,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void fused_adamw_vec_kernel(const T* __restrict__ grad, float* __restrict__ master,
                                                               float* __restrict__ m, float* __restrict__ v,
                                                               T* __restrict__ param_out, long long n8, AdamWArgs a) {
+  if (a.clip_dev) a.clip *= *a.clip_dev;
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
   for (long long c = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; c < n8; c += stride) {
     float g[8], mm[8], vv[8], w[8];

@@ -17,7 +17,9 @@ directly into the flat bucket (``param.grad`` is a view), and a bucket's
 reduce-scatter is launched from a post-accumulate hook as soon as its last
 gradient lands, on a side stream, so communication overlaps the rest of backward.
 Gradient clipping uses the global norm assembled from the shards with one scalar
-all-reduce.  The reference trains single-process (train_hidden_adapter.py:320-359).
+all-reduce; norm and clip factor stay on the device (the fused AdamW kernel reads the
+factor), and each bucket's all-gather runs on the communication stream under the next
+bucket's AdamW.  The reference trains single-process (train_hidden_adapter.py:320-359).
 """
 from __future__ import annotations
 
@@ -89,8 +91,12 @@ class ShardedAdamW:
             cur_bytes += nbytes
         if cur:
             self.buckets.append(_Bucket(cur, self.world, self.rank))
-        self.overlap = overlap and self.distributed and plist[0].is_cuda
-        self.comm_stream = torch.cuda.Stream() if self.overlap else None
+        # RCCL collectives run on a side stream (default priority).  A gloo group is given host
+        # tensors only (shards on a GPU are staged through synchronous host copies) and never overlaps.
+        self.backend = dist.get_backend(group) if self.distributed else None
+        self.on_rccl = self.distributed and plist[0].is_cuda and self.backend == "nccl"
+        self.overlap = overlap and self.on_rccl
+        self.comm_stream = torch.cuda.Stream() if self.on_rccl else None
         self._owner: Dict[int, _Bucket] = {}
         for b in self.buckets:
             for p in b.params:
@@ -114,11 +120,16 @@ class ShardedAdamW:
     def _launch_reduce(self, b: _Bucket) -> None:
         if not self.distributed or self.world == 1:
             return      # grad_shard aliases the flat gradient
-        if self.comm_stream is not None:
+        if self.on_rccl:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 b.work = dist.reduce_scatter_tensor(b.grad_shard, b.flat_grad, op=dist.ReduceOp.AVG,
                                                     group=self.group, async_op=True)
+        elif b.flat_grad.is_cuda:                      # gloo: host tensors only
+            src = b.flat_grad.cpu()
+            dst = torch.empty(b.shard_len, dtype=src.dtype)
+            dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=self.group)
+            b.grad_shard.copy_(dst.div_(self.world))
         else:
             dist.reduce_scatter_tensor(b.grad_shard, b.flat_grad, op=dist.ReduceOp.SUM,
                                        group=self.group)
@@ -126,13 +137,11 @@ class ShardedAdamW:
 
     def _finish_reduces(self) -> None:
         for b in self.buckets:
-            if self.overlap:
-                if b.work is None:        # a parameter received no gradient this step
-                    self._launch_reduce(b)
-                if b.work is not None:    # (a one-rank group has nothing in flight)
-                    b.work.wait()
-            else:
+            if b.work is None:            # not launched from a hook (no overlap, or a parameter without gradient)
                 self._launch_reduce(b)
+            if b.work is not None:        # (a one-rank group has nothing in flight)
+                b.work.wait()
+                b.work = None
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
@@ -142,54 +151,85 @@ class ShardedAdamW:
             b.flat_grad.zero_()
         self._arm()
 
-    def global_grad_norm(self) -> float:
+    def _global_sq_norm(self) -> torch.Tensor:
+        """Squared global gradient norm as a 0-d fp32 tensor on the shards' device (summed over
+        ranks).  Stays on the device with RCCL; a gloo group gets host tensors only."""
         sq = torch.zeros((), dtype=torch.float32, device=self.buckets[0].grad_shard.device)
         for b in self.buckets:
             sq += torch.linalg.vector_norm(b.grad_shard, dtype=torch.float32).square()
-        if self.distributed:
+        if self.distributed and self.world > 1:
             if dist.get_backend(self.group) == "gloo" and sq.is_cuda:
                 host = sq.cpu()
                 dist.all_reduce(host, group=self.group)
-                sq = host
+                sq = host.to(sq.device)
             else:
                 dist.all_reduce(sq, group=self.group)
-        return float(sq.sqrt())
+        return sq
+
+    def global_grad_norm(self) -> float:
+        return float(self._global_sq_norm().sqrt())
+
+    def _gather(self, b: _Bucket, new_shard: torch.Tensor) -> None:
+        """All-gather the refreshed shards of one bucket.  On a GPU it goes to the communication
+        stream, so the next bucket's AdamW runs while this bucket's shards travel."""
+        if self.on_rccl:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                b.work = dist.all_gather_into_tensor(b.flat_param, new_shard, group=self.group, async_op=True)
+        elif new_shard.is_cuda:                        # gloo: host tensors only
+            full = torch.empty(b.padded, dtype=new_shard.dtype)
+            dist.all_gather_into_tensor(full, new_shard.cpu(), group=self.group)
+            b.flat_param.copy_(full)
+        else:
+            dist.all_gather_into_tensor(b.flat_param, new_shard, group=self.group)
 
     @torch.no_grad()
-    def step(self, max_grad_norm: Optional[float] = None) -> float:
-        """Reduce-scatter (if not already in flight), clip, AdamW on the shard,
-        all-gather.  Returns the global gradient norm before clipping."""
+    def step(self, max_grad_norm: Optional[float] = None) -> torch.Tensor:
+        """Reduce-scatter (if not already in flight), clip, AdamW on the shard, all-gather.
+        Returns the global gradient norm before clipping as a 0-d tensor: the clip factor is
+        computed and consumed on the device (the fused AdamW kernel reads it), so a step on
+        RCCL makes no host round trip unless the caller converts the norm (``float(norm)``)."""
         self._finish_reduces()
-        norm = self.global_grad_norm()
-        clip = 1.0
-        if max_grad_norm is not None and norm > max_grad_norm:
-            clip = max_grad_norm / (norm + 1e-6)
+        norm = self._global_sq_norm().sqrt()
+        clip_t = None
+        if max_grad_norm is not None:
+            clip_t = (max_grad_norm / (norm + 1e-6)).clamp(max=1.0).reshape(1)
         self.step_count += 1
         lr = self.param_groups[0]["lr"]
         b1, b2 = self.betas
         bc1 = 1 - b1 ** self.step_count
         bc2 = 1 - b2 ** self.step_count
+        gather = self.distributed and self.world > 1
         for b in self.buckets:
+            b.work = None
             if b.master.is_cuda and b.flat_param.dtype in (torch.bfloat16, torch.float32):
                 # one pass over the shard (csrc/kernels/optim.hip) instead of ten launches
                 from ..ops import hip
-                new_shard = b.flat_param[b.shard_slice] if not self.distributed else b.new_shard
+                new_shard = b.new_shard if gather else b.flat_param[b.shard_slice]
                 hip.raw.fused_adamw(b.grad_shard, b.master, b.exp_avg, b.exp_avg_sq, new_shard, lr, b1, b2,
-                                    self.eps, self.weight_decay, self.step_count, clip)
-                if self.distributed:
-                    dist.all_gather_into_tensor(b.flat_param, new_shard, group=self.group)
+                                    self.eps, self.weight_decay, self.step_count, 1.0, clip_t)
+                if gather:
+                    self._gather(b, new_shard)
                 continue
-            g = b.grad_shard.float() * clip
+            g = b.grad_shard.float()
+            if clip_t is not None:
+                g = g * clip_t.to(g.device)
             b.master.mul_(1 - lr * self.weight_decay)
             b.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
             b.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
             denom = (b.exp_avg_sq.sqrt() / math.sqrt(bc2)).add_(self.eps)
             b.master.addcdiv_(b.exp_avg, denom, value=-lr / bc1)
             new_shard = b.master.to(b.flat_param.dtype)
-            if self.distributed:
-                dist.all_gather_into_tensor(b.flat_param, new_shard, group=self.group)
+            if gather:
+                self._gather(b, new_shard)
             else:
                 b.flat_param[b.shard_slice].copy_(new_shard)
+        for b in self.buckets:                      # parameters are whole again before the next forward
+            if b.work is not None:
+                b.work.wait()
+                b.work = None
+        if self.comm_stream is not None and gather:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
         return norm
 
     # ------------------------------------------------------------- checkpointing

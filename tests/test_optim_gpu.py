@@ -54,7 +54,7 @@ def test_sharded_adamw_on_gpu_matches_torch(dtype):
             p.grad.copy_(gr.to(dev))
             r.grad = gr.float().clone()
         want_norm = float(torch.nn.utils.clip_grad_norm_(ref, 1.0))
-        norm = opt.step(max_grad_norm=1.0)
+        norm = float(opt.step(max_grad_norm=1.0))
         ropt.step()
         assert abs(norm - want_norm) < 1e-3 * want_norm
     for p, r in zip(params, ref):
