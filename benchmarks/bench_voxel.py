@@ -38,5 +38,28 @@ def main():
               f"({n / res[True][0] / 1e6:.1f} G events/s), whole call incl. bounds + output zeroing", flush=True)
 
 
+def sweep():
+    """LDS-band kernel only: event chunks per (band, bin)."""
+    n = 10_000_000
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    ev = {"x": torch.randint(0, 640, (n,), device=dev, generator=g, dtype=torch.int32),
+          "y": torch.randint(0, 480, (n,), device=dev, generator=g, dtype=torch.int32),
+          "p": torch.randint(0, 2, (n,), device=dev, generator=g, dtype=torch.int32),
+          "t": torch.arange(n, device=dev, dtype=torch.int64)}
+    for chunks in (1, 2, 3, 4, 6, 10, 16):
+        for _ in range(2):
+            eo.voxel_grid_gpu(ev, 5, (480, 640), by="count", privatised=True, chunks=chunks)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            eo.voxel_grid_gpu(ev, 5, (480, 640), by="count", privatised=True, chunks=chunks)
+        torch.cuda.synchronize()
+        print(f"chunks {chunks}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms", flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+        sweep()
+        sys.exit(0)
     main()

@@ -773,7 +773,8 @@ std::tuple<Tensor, Tensor> event_voxel(const Tensor& x, const Tensor& y, const T
 // Same outputs for a stream whose bins are index ranges: bounds int32 [bins+1] on the device,
 // non-decreasing, bounds[0] >= 0, bounds[bins] <= n (checked by the caller that built them).
 std::tuple<Tensor, Tensor> event_voxel_ranges(const Tensor& x, const Tensor& y, const Tensor& p,
-                                              const Tensor& bounds, int64_t H, int64_t W, bool signed_mode) {
+                                              const Tensor& bounds, int64_t H, int64_t W, bool signed_mode,
+                                              int64_t chunks) {
   check_i32(x, "x"); check_i32(y, "y"); check_i32(p, "p"); check_i32(bounds, "bounds");
   const int64_t n = x.numel(), bins = bounds.numel() - 1;
   TORCH_CHECK(y.numel() == n && p.numel() == n && bins >= 1 && H >= 1 && W >= 1);
@@ -784,7 +785,7 @@ std::tuple<Tensor, Tensor> event_voxel_ranges(const Tensor& x, const Tensor& y, 
   if (n > 0)
     evgpt::launch_event_voxel_ranges(x.data_ptr<int>(), y.data_ptr<int>(), p.data_ptr<int>(), bounds.data_ptr<int>(),
                                      (int)n, (int)bins, (int)H, (int)W, hist.data_ptr<int>(), vox.data_ptr<float>(),
-                                     signed_mode ? 1 : 0, cur_stream());
+                                     signed_mode ? 1 : 0, cur_stream(), (int)std::min<int64_t>(std::max<int64_t>(chunks, 0), 1024));
   return {hist, vox};
 }
 
@@ -974,7 +975,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("linear_argmax_partials(Tensor x, Tensor w, Tensor? bias) -> (Tensor, Tensor)", &linear_argmax_partials);
   m.def("event_raster(Tensor x, Tensor y, Tensor p, int n_slices, int H, int W, int mode) -> Tensor", &event_raster);
   m.def("event_voxel(Tensor x, Tensor y, Tensor p, Tensor t, int t0, int span, int bins, int H, int W, bool signed_mode, bool by_count) -> (Tensor, Tensor)", &event_voxel);
-  m.def("event_voxel_ranges(Tensor x, Tensor y, Tensor p, Tensor bounds, int H, int W, bool signed_mode) -> (Tensor, Tensor)", &event_voxel_ranges);
+  m.def("event_voxel_ranges(Tensor x, Tensor y, Tensor p, Tensor bounds, int H, int W, bool signed_mode, int chunks=0) -> (Tensor, Tensor)", &event_voxel_ranges);
   m.def("clip_preprocess(Tensor img, Tensor hstart, Tensor hcount, Tensor hweight, Tensor vstart, Tensor vcount, Tensor vweight, int S, int resize_h, int resize_w, int top, int left, float[] mean, float[] stdv) -> Tensor", &clip_preprocess);
   m.def("gemm_force_config(int cfg) -> ()", &gemm_force_config);
   m.def("gemm_force_splitk(int sk) -> ()", &gemm_force_splitk);

@@ -73,7 +73,7 @@ void launch_event_raster(const int* x, const int* y, const int* p, int n_events,
 int event_voxel_band_rows(int H, int W);
 void launch_event_voxel_ranges(const int* x, const int* y, const int* p, const int* bounds, int n_events,
                                int bins, int H, int W, int* out_hist, float* out_vox, int signed_mode,
-                               hipStream_t st);
+                               hipStream_t st, int chunks_override = 0);
 void launch_event_voxel(const int* x, const int* y, const int* p, const long long* t, int n_events,
                         long long t0, long long span, int bins, int H, int W, int* out_hist,
                         float* out_vox, int signed_mode, int by_count, hipStream_t st);

@@ -58,15 +58,28 @@ def _bin_bounds(ev: Dict[str, torch.Tensor], bins: int, by: str, t0: int, span: 
     t = ev["t"]
     if n > 1 and not bool((t[1:] >= t[:-1]).all()):
         return None
-    # the kernel's own arithmetic (double): bin = clamp(int((t - t0) / span * bins))
-    which = ((t - t0).to(torch.float64) / float(span) * bins).to(torch.int64).clamp_(0, bins - 1)
-    edges = torch.arange(bins + 1, dtype=torch.int64, device=dev)
-    return torch.searchsorted(which, edges).to(torch.int32)
+    # first timestamp of every bin under the kernel's own arithmetic (IEEE double, same operation
+    # order): bin(t) = clamp(int((t - t0) / span * bins)); start from the real-valued edge and
+    # step to the exact integer boundary
+    def which(ts: int) -> int:
+        return min(max(int(float(ts - t0) / float(span) * bins), 0), bins - 1)
+    edges = [t0]
+    for b in range(1, bins):
+        e = t0 + (b * span) // bins
+        while which(e) >= b and e > t0:
+            e -= 1
+        while which(e) < b:
+            e += 1
+        edges.append(e)
+    first = torch.searchsorted(t, torch.tensor(edges, dtype=t.dtype, device=dev))
+    first[0] = 0
+    return torch.cat([first, first.new_tensor([n])]).to(torch.int32)
 
 
 def voxel_grid_gpu(ev: Dict[str, torch.Tensor], bins: int = 5,
                    size: Optional[Tuple[int, int]] = None, signed: bool = True,
-                   by: str = "time", privatised: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                   by: str = "time", privatised: Optional[bool] = None,
+                   chunks: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
     """``(hist int32 [bins,2,H,W], voxel fp32 [bins,H,W])``.
 
     Two kernels produce the same numbers: one global atomic per event, and (``privatised``,
@@ -83,7 +96,7 @@ def voxel_grid_gpu(ev: Dict[str, torch.Tensor], bins: int = 5,
         bounds = _bin_bounds(ev, bins, by, t0, span)
         if bounds is not None:
             x, y, p = (a if a.data_ptr() % 16 == 0 else a.clone() for a in (ev["x"], ev["y"], ev["p"]))
-            return hip.raw.event_voxel_ranges(x, y, p, bounds, size[0], size[1], signed)
+            return hip.raw.event_voxel_ranges(x, y, p, bounds, size[0], size[1], signed, chunks)
     return hip.raw.event_voxel(ev["x"], ev["y"], ev["p"], ev["t"], t0, span, bins, size[0],
                                size[1], signed, by == "count")
 
