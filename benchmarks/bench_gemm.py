@@ -21,7 +21,7 @@ SHAPES = [  # (M, N, K, label)
     (4643, 4096, 11008, "8f down"), (20352, 4096, 4096, "bs32 prefill o_proj"),
     (32, 4096, 4096, "bs32 o_proj"), (3200, 4096, 256, "adapter up"), (3200, 256, 4096, "adapter down"),
 ]
-CFGS = {0: "128x128s2", 1: "64x128s3", 2: "64x64s4", 3: "32x64s4", 4: "32x128s4"}
+CFGS = {0: "128x128s2", 1: "64x128s3", 2: "64x64s4", 3: "32x64s4", 4: "32x128s4", 5: "256x256w8"}
 
 
 def timeit(fn, iters=20):

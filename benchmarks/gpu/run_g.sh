@@ -1,0 +1,21 @@
+#!/bin/bash
+# GPU session G: the 256x256 8-wave GEMM: numerics, then throughput next to the other configs.
+set -u
+mkdir -p gpurun_out
+ROOT=$PWD
+step() {  # step <limit_s> <log> <cmd...>
+  local lim=$1 log=$2; shift 2
+  echo "== $* (limit ${lim}s)" | tee -a $ROOT/gpurun_out/session.log
+  timeout -k 10 "$lim" "$@" > "$ROOT/gpurun_out/$log" 2>&1
+  local rc=$?
+  echo "   rc=$rc" | tee -a $ROOT/gpurun_out/session.log
+  if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then echo "ABORT after $log (rc=$rc)" | tee -a $ROOT/gpurun_out/session.log; tail -30 "$ROOT/gpurun_out/$log"; exit $rc; fi
+  return $rc
+}
+PT="python -u -m pytest -x -v --timeout 120 --timeout-method thread"
+step 300 t_g256.log $PT tests/test_gemm256_gpu.py || { grep -E "PASSED|FAILED|^E  " gpurun_out/t_g256.log | tail -40; exit 1; }
+grep -E "passed|failed" gpurun_out/t_g256.log | tail -3
+step 300 t_ops.log $PT tests/test_ops_gpu.py tests/test_train_kernels_gpu.py -q || { grep -E "FAILED|^E  " gpurun_out/t_ops.log | tail -40; exit 1; }
+grep -E "passed|failed" gpurun_out/t_ops.log | tail -3
+step 400 b_gemm.log python benchmarks/bench_gemm.py
+tail -30 gpurun_out/b_gemm.log

@@ -36,6 +36,8 @@
 // K-contiguous operand, so any mix of layouts feeds the same MFMA.  The image is
 // XOR-swizzled (on the source address and on the read) so that the 8 k-rows a half-wave
 // gathers at once fall on 8 distinct 32-byte bank slots.
+#include <type_traits>
+
 #include "common.h"
 #include "../evgpt_kernels.h"
 
@@ -111,6 +113,99 @@ __device__ __forceinline__ bf16x8_t frag_t(const unsigned char* tile, int cb, in
   const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)a2);
   const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// Epilogue shared by the GEMM kernels: lane holds C[m][n .. n+3] of each 16x16 tile (m = row
+// lane & 15, n = 4 * (lane >> 4)); wave (wr, wc) owns the WM x WN sub-tile at (wr*WM, wc*WN).
+template <int TM, int TN, int WM, int WN, int WGN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc)[TM][TN], int m0, int n0, int wr,
+                                              int wc, int tn, int tiles_n, int ksplit, int lane) {
+  const int frow = lane & 15, fq = lane >> 4;
+  if (p.splitk > 1 || p.raw_partial) {
+    float* slab = p.partial + static_cast<size_t>(ksplit) * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wr * WM + i * 16 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wc * WN + j * 16 + fq * 4;
+        float* dst = slab + static_cast<size_t>(m) * p.N + n;
+        if (n + 3 < p.N && (p.N & 3) == 0) {
+          *reinterpret_cast<f32x4_t*>(dst) = acc[i][j];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wr * WM + i * 16 + frow;
+    if (p.amax_val) {
+      // row max over this wave's WN columns: in-lane over j and r, then across the
+      // 4 lanes (fq) that share the row
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wc * WN + j * 16 + fq * 4 + r;
+          float v = acc[i][j][r];
+          if (p.bias && n < p.N) v += bf16_to_f32(p.bias[n]);
+          if (n < p.N && (v > bv || (v == bv && n < bi))) { bv = v; bi = n; }
+        }
+#pragma unroll
+      for (int off = 16; off < 64; off <<= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (fq == 0 && m < p.M) {
+        const int n_part = tiles_n * WGN;
+        p.amax_val[static_cast<size_t>(m) * n_part + tn * WGN + wc] = bv;
+        p.amax_idx[static_cast<size_t>(m) * n_part + tn * WGN + wc] = bi;
+      }
+    }
+    if (m >= p.M || (!p.C && !p.Cf)) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wc * WN + j * 16 + fq * 4;
+      if (n >= p.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const size_t o = static_cast<size_t>(m) * p.ldc + n;
+      const bool full = (n + 3 < p.N) && ((p.ldc & 3) == 0);
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += bf16_to_f32(p.bias[n + r]);
+      }
+      if (p.act != ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+      }
+      if (p.res) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) v[r] = bf16_to_f32(f32_to_bf16(v[r])) + bf16_to_f32(p.res[o + r]);
+      }
+      if (p.Cf) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < p.N) p.Cf[o + r] = v[r];
+      }
+      if (p.C) {
+        if (full) {
+          u32x2_t w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2_t*>(p.C + o) = w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < p.N) p.C[o + r] = f32_to_bf16(v[r]);
+        }
+      }
+    }
+  }
 }
 
 // 16 bytes per lane from `src + voff` (range-checked against `bytes`: past it, zeros) straight
@@ -265,92 +360,216 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
 
-  // ---- epilogue: lane holds C[m][n .. n+3]
-  if (p.splitk > 1 || p.raw_partial) {
-    float* slab = p.partial + static_cast<size_t>(ksplit) * p.M * p.N;
+  gemm_epilogue<TM, TN, WM, WN, WGN>(p, acc, m0, n0, wr, wc, tn, tiles_n, ksplit, lane);
+}
+
+// ---------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 x 4, each 128 x 64 of C), one workgroup per CU: the kernel
+// for GEMMs with thousands of rows.  The 4-wave kernel above stops near 900 TFLOP/s however it
+// is pipelined, because one wave per SIMD has to alternate between feeding the LDS pipe and
+// the MFMA pipe; here each SIMD holds two waves that run HALF A PHASE APART, so one issues
+// MFMAs while the other issues its LDS reads and the staging loads.
+//
+// A K-tile is four phases; a phase is  [LDS reads + staging loads] barrier [16 MFMAs] barrier.
+// The two wave rows (wr = 0 / 1) are offset by one barrier: wr = 1 passes one extra barrier
+// before the loop and wr = 0 one after it, so between any two barriers one row is in its MFMA
+// part and the other in its load part.
+//
+// LDS (128 KB) holds two K-tiles, each as four 16 KB images: A-sub0, A-sub1, W-sub0, W-sub1.
+// "sub h" is what the phases consume together: A-sub h = rows {wr*128 + h*64 .. +64} of both wave
+// rows (128 rows), W-sub h = columns {wc*64 + h*32 .. +32} of the four wave columns (128 rows of W).
+//   phase 1: read W-sub0 + A-sub0      MFMA A0 x W0     stage A-sub1 of tile t+1
+//   phase 2: read W-sub1               MFMA A0 x W1
+//   phase 3: read A-sub1               MFMA A1 x W1     stage W-sub0, A-sub0 of tile t+2
+//   phase 4: (operands in registers)   MFMA A1 x W0     stage W-sub1 of tile t+2, then wait
+// Ordering rules this schedule is built on (P = phase counter over the whole loop):
+//   * an image read in phase P is re-staged in phase P+2 or later: the reading wave row may
+//     be the late one, whose reads have returned only when it reaches the first barrier of
+//     its phase P+1, which is the second barrier of the early row's phase P+1;
+//   * staged data is read one phase after the wait that retires it: every wave waits
+//     (counted vmcnt: the three youngest images stay in flight) before the first barrier of
+//     its phase 4, and the reads of the next tile start after that phase's second barrier,
+//     which no wave passes before both rows have done their wait.
+// Loads past the end of K are issued anyway: the buffer descriptor's range check turns them
+// into zero fills of images nobody reads, which keeps the vmcnt arithmetic uniform.
+template <bool AT, bool BT>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, HALF = 16384, TILE = 4 * HALF;
+  constexpr int TM = 8, TN = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n * p.splitk);
+  const int tile = bid / p.splitk, ksplit = bid % p.splitk;
+  const int k_begin = ksplit * p.k_per_split;
+  const int k_len = min(p.k_per_split, p.K - k_begin);
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = k_len / BK;
+
+  // ---- staging: image = 16 wave-instructions of 1 KB, two per wave.  Per-lane source offsets
+  // of sub 0 are computed once; sub 1 and the K-tile move the (scalar) descriptor base.
+  int voff_a[2], voff_w[2];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wr * WM + i * 16 + frow;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wc * WN + j * 16 + fq * 4;
-        float* dst = slab + static_cast<size_t>(m) * p.N + n;
-        if (n + 3 < p.N && (p.N & 3) == 0) {
-          *reinterpret_cast<f32x4_t*>(dst) = acc[i][j];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = acc[i][j][r];
-        }
-      }
+  for (int i = 0; i < 2; ++i) {
+    const int rg = wid * 2 + i;
+    if constexpr (AT) {      // image [64 k][128 columns]: columns = two runs of 64 (wave rows 0 / 1)
+      const int lin = rg * 64 + lane;
+      const int row = lin >> 4, cl = (lin & 15) ^ swz_t<128>(row);
+      voff_a[i] = (row * p.lda + m0 + (cl >> 3) * 128 + (cl & 7) * 8) * 2;
+    } else {                 // image [128 rows][64 k]
+      const int lr = rg * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((lr >> 1) & 7);
+      voff_a[i] = ((m0 + (lr >> 6) * 128 + (lr & 63)) * p.lda + c * 8) * 2;
     }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wr * WM + i * 16 + frow;
-    if (p.amax_val) {
-      // row max over this wave's WN columns: in-lane over j and r, then across the
-      // 4 lanes (fq) that share the row
-      float bv = -INFINITY;
-      int bi = 0x7fffffff;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = n0 + wc * WN + j * 16 + fq * 4 + r;
-          float v = acc[i][j][r];
-          if (p.bias && n < p.N) v += bf16_to_f32(p.bias[n]);
-          if (n < p.N && (v > bv || (v == bv && n < bi))) { bv = v; bi = n; }
-        }
-#pragma unroll
-      for (int off = 16; off < 64; off <<= 1) {
-        const float ov = __shfl_xor(bv, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-      }
-      if (fq == 0 && m < p.M) {
-        const int n_part = tiles_n * WGN;
-        p.amax_val[static_cast<size_t>(m) * n_part + tn * WGN + wc] = bv;
-        p.amax_idx[static_cast<size_t>(m) * n_part + tn * WGN + wc] = bi;
-      }
-    }
-    if (m >= p.M || (!p.C && !p.Cf)) continue;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wc * WN + j * 16 + fq * 4;
-      if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      const size_t o = static_cast<size_t>(m) * p.ldc + n;
-      const bool full = (n + 3 < p.N) && ((p.ldc & 3) == 0);
-      if (p.bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += bf16_to_f32(p.bias[n + r]);
-      }
-      if (p.act != ACT_NONE) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
-      }
-      if (p.res) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.N) v[r] = bf16_to_f32(f32_to_bf16(v[r])) + bf16_to_f32(p.res[o + r]);
-      }
-      if (p.Cf) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (n + r < p.N) p.Cf[o + r] = v[r];
-      }
-      if (p.C) {
-        if (full) {
-          u32x2_t w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<u32x2_t*>(p.C + o) = w;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (n + r < p.N) p.C[o + r] = f32_to_bf16(v[r]);
-        }
-      }
+    if constexpr (BT) {      // columns = four runs of 32 (wave columns 0..3)
+      const int lin = rg * 64 + lane;
+      const int row = lin >> 4, cl = (lin & 15) ^ swz_t<128>(row);
+      voff_w[i] = (row * p.ldw + n0 + (cl >> 2) * 64 + (cl & 3) * 8) * 2;
+    } else {
+      const int lr = rg * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((lr >> 1) & 7);
+      voff_w[i] = ((n0 + (lr >> 5) * 64 + (lr & 31)) * p.ldw + c * 8) * 2;
     }
   }
+  const long long bytes_a = 2ll * (AT ? p.ka_rows : p.M) * p.lda;
+  const long long bytes_w = 2ll * (BT ? p.kw_rows : p.N) * p.ldw;
+  // which: 0 = A-sub0, 1 = A-sub1, 2 = W-sub0, 3 = W-sub1; kt may run past nk (zero fill)
+  auto stage = [&](int which, int kt) {
+    const int k0 = k_begin + kt * BK, h = which & 1;
+    unsigned char* dst = smem + (kt & 1) * TILE + which * HALF + wid * 2048;
+    if (which < 2) {
+      const long long adv = AT ? 2ll * k0 * p.lda + 2ll * h * 64 : 2ll * k0 + 2ll * h * 64 * p.lda;
+      const long long left = bytes_a - adv;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(p.A) + adv;
+      const int lim = static_cast<int>(left > 0 ? left : 0);
+      buffer_to_lds16(src, lim, dst, voff_a[0]);
+      buffer_to_lds16(src, lim, dst + 1024, voff_a[1]);
+    } else {
+      const long long adv = BT ? 2ll * k0 * p.ldw + 2ll * h * 32 : 2ll * k0 + 2ll * h * 32 * p.ldw;
+      const long long left = bytes_w - adv;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(p.W) + adv;
+      const int lim = static_cast<int>(left > 0 ? left : 0);
+      buffer_to_lds16(src, lim, dst, voff_w[0]);
+      buffer_to_lds16(src, lim, dst + 1024, voff_w[1]);
+    }
+  };
+
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int fsw = (frow >> 1) & 7;
+  // per-lane read offsets inside an image (K-contiguous operands), one per 32-wide k-step
+  const int rd_a[2] = {(wr * 64 + frow) * 128 + ((fq ^ fsw) << 4), (wr * 64 + frow) * 128 + (((4 + fq) ^ fsw) << 4)};
+  const int rd_w[2] = {(wc * 32 + frow) * 128 + ((fq ^ fsw) << 4), (wc * 32 + frow) * 128 + (((4 + fq) ^ fsw) << 4)};
+
+  bf16x8_t af[2][4][2], wf[2][2][2];     // [sub][16-row tile][k-step]
+  auto read_a = [&](int buf, int h) {
+    const unsigned char* img = smem + buf * TILE + h * HALF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (AT) af[h][i][ks] = frag_t<128>(img, wr * 64 + i * 16, ks, lane);
+        else af[h][i][ks] = *reinterpret_cast<const bf16x8_t*>(img + rd_a[ks] + i * 2048);
+      }
+  };
+  auto read_w = [&](int buf, int h) {
+    const unsigned char* img = smem + buf * TILE + (2 + h) * HALF;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if constexpr (BT) wf[h][j][ks] = frag_t<128>(img, wc * 32 + j * 16, ks, lane);
+        else wf[h][j][ks] = *reinterpret_cast<const bf16x8_t*>(img + rd_w[ks] + j * 2048);
+      }
+  };
+  auto mma = [&](int ha, int hw) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[ha * 4 + i][hw * 2 + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[hw][j][ks], af[ha][i][ks], acc[ha * 4 + i][hw * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // workgroup barrier that neither the compiler's passes nor its scheduler move code across
+  auto fence = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: tile 0 whole, then the three images of tile 1 the steady state keeps in flight
+  stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+  stage(2, 1); stage(0, 1); stage(3, 1);
+  wait_vm<6>();
+  fence();
+  if (wr == 1) fence();
+
+  auto tile_body = [&](auto buf_c, int kt) {
+    constexpr int buf = decltype(buf_c)::value;
+    // phase 1
+    read_w(buf, 0);
+    read_a(buf, 0);
+    stage(1, kt + 1);
+    fence();
+    mma(0, 0);
+    fence();
+    // phase 2
+    read_w(buf, 1);
+    fence();
+    mma(0, 1);
+    fence();
+    // phase 3
+    read_a(buf, 1);
+    stage(2, kt + 2);
+    stage(0, kt + 2);
+    fence();
+    mma(1, 1);
+    fence();
+    // phase 4
+    stage(3, kt + 2);
+    wait_vm<6>();
+    fence();
+    mma(1, 0);
+    fence();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    tile_body(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) tile_body(std::integral_constant<int, 1>{}, kt + 1);
+  }
+  if (wr == 0) fence();
+  wait_vm<0>();   // zero fills past K must have landed before the workgroup's LDS is handed on
+
+  gemm_epilogue<TM, TN, 128, 64, 4>(p, acc, m0, n0, wr, wc, tn, tiles_n, ksplit, lane);
+}
+
+static bool g_use_256 = true;
+void gemm_enable_256(bool on) { g_use_256 = on; }
+
+template <bool AT, bool BT>
+static void launch_256(const GemmParams& p, hipStream_t st) {
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256) * p.splitk;
+  constexpr int smem = 128 * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<AT, BT>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm256_kernel<AT, BT>), dim3(tiles), dim3(512), smem, st, p);
 }
 
 // out = act(sum_s partial[s] + bias) + res, 4 columns per thread
@@ -402,10 +621,19 @@ static void launch_cfg(const GemmParams& p, hipStream_t st) {
 // CUs; shapes that cannot (prefill of a few hundred rows against a 1024- or
 // 4096-wide matrix, verify batches) take smaller tiles with a deeper ring, since
 // a grid below one block per CU is bound by the latency of its own K loop.
-enum GemmCfg { CFG_128x128 = 0, CFG_64x128 = 1, CFG_64x64 = 2, CFG_32x64 = 3, CFG_32x128 = 4 };
+enum GemmCfg { CFG_128x128 = 0, CFG_64x128 = 1, CFG_64x64 = 2, CFG_32x64 = 3, CFG_32x128 = 4, CFG_256x256 = 5 };
 
 static int g_forced_cfg = -1;
 void gemm_force_config(int cfg) { g_forced_cfg = cfg; }
+
+// The 8-wave kernel pays once there are rows to fill 256-row tiles and about half a round of
+// tiles (measured on MI355X, TFLOP/s, 8-wave vs best 4-wave config: 2115 x 4096 x 11008, 144 tiles,
+// 913 vs 751; 4643 x 12288 x 4096 1190 vs 930; 20352 x 4096 x 4096 1230 vs 905; but 636 rows 717 vs
+// 948 and 2885 x 1024 x 4096, 48 tiles, 282 vs 567).
+static bool use_256(int M, int N) {
+  const long long t = static_cast<long long>((M + 255) / 256) * ((N + 255) / 256);
+  return g_use_256 && M >= 1024 && t >= 128;
+}
 
 static GemmCfg pick_cfg(int M, int N) {
   if (g_forced_cfg >= 0) return static_cast<GemmCfg>(g_forced_cfg);
@@ -414,6 +642,7 @@ static GemmCfg pick_cfg(int M, int N) {
   };
   // thresholds from benchmarks/bench_gemm.py on MI355X
   if (M <= 32) return tiles(32, 128) >= 256 ? CFG_32x128 : CFG_32x64;
+  if (use_256(M, N)) return CFG_256x256;
   if (tiles(128, 128) >= 384) return CFG_128x128;
   if (tiles(64, 128) >= 300) return CFG_64x128;
   if (tiles(64, 64) >= 300) return CFG_64x64;
@@ -421,7 +650,7 @@ static GemmCfg pick_cfg(int M, int N) {
 }
 
 static long long cfg_tiles(GemmCfg c, int M, int N) {
-  static const int bm[] = {128, 64, 64, 32, 32}, bn[] = {128, 128, 64, 64, 128};
+  static const int bm[] = {128, 64, 64, 32, 32, 256}, bn[] = {128, 128, 64, 64, 128, 256};
   return static_cast<long long>((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]);
 }
 
@@ -449,6 +678,7 @@ int gemm_splitk(int M, int N, int K) {
 
 int gemm_argmax_partials(int M, int N) {
   switch (pick_cfg(M, N)) {  // tiles_n * WGN of the chosen config
+    case CFG_256x256: return ((N + 255) / 256) * 4;
     case CFG_128x128: case CFG_64x128: return ((N + 127) / 128) * 2;
     case CFG_64x64: return ((N + 63) / 64) * 2;
     case CFG_32x64: return ((N + 63) / 64) * 4;
@@ -474,6 +704,7 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
     case CFG_64x128: launch_cfg<64, 128, 2, 2, 3>(p, st); break;
     case CFG_64x64: launch_cfg<64, 64, 2, 2, 4>(p, st); break;
     case CFG_32x64: launch_cfg<32, 64, 1, 4, 4>(p, st); break;
+    case CFG_256x256: launch_256<false, false>(p, st); break;
     default: launch_cfg<32, 128, 1, 4, 4>(p, st); break;
   }
   if (p.splitk > 1) {
@@ -493,7 +724,9 @@ static void launch_t(const GemmParams& p, hipStream_t st) {
   auto tiles = [&](int bm, int bn) {
     return static_cast<long long>((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
   };
-  if (tiles(128, 128) >= 384) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
+  const bool cols_ok = (!AT || p.M % 8 == 0) && (!BT || p.N % 8 == 0);
+  if ((g_forced_cfg == CFG_256x256 || (g_forced_cfg < 0 && use_256(p.M, p.N))) && cols_ok) launch_256<AT, BT>(p, st);
+  else if (tiles(128, 128) >= 384) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
   else if (tiles(64, 128) >= 300) launch_cfg<64, 128, 2, 2, 3, AT, BT>(p, st);
   else launch_cfg<64, 64, 2, 2, 4, AT, BT>(p, st);
 }
@@ -526,6 +759,7 @@ int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M,
     case CFG_64x128: launch_cfg<64, 128, 2, 2, 3>(p, st); break;
     case CFG_64x64: launch_cfg<64, 64, 2, 2, 4>(p, st); break;
     case CFG_32x64: launch_cfg<32, 64, 1, 4, 4>(p, st); break;
+    case CFG_256x256: launch_256<false, false>(p, st); break;
     default: launch_cfg<32, 128, 1, 4, 4>(p, st); break;
   }
   return p.splitk;

@@ -1,0 +1,98 @@
+"""The 256 x 256 8-wave GEMM (phase-staggered wave rows) forced onto shapes that exercise its edges:
+rows / columns that do not fill a tile, one K-tile, odd and even K-tile counts, every epilogue, the
+K-strided operand layouts of the backward products; each against an fp32 matmul.  Every case runs
+several times: its synchronisation is counted waits and barriers, so a race would show as a
+difference between repeats."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device=dev).manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, device=dev, generator=g) * scale).to(torch.bfloat16)
+
+
+@pytest.fixture()
+def force256():
+    from eventgpt_amd.ops import hip
+    hip.raw.gemm_force_config(5)
+    yield hip.raw
+    hip.raw.gemm_force_config(-1)
+
+
+def _check(y, want, K):
+    err = (y.float() - want).abs()
+    tol = 2e-2 * math.sqrt(K / 64) * float(want.abs().max()) / 8 + 2e-2 * want.abs()
+    assert bool((err <= tol).all()), (float(err.max()), float(want.abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (256, 256, 192), (512, 768, 4096), (1000, 520, 1024),
+                                   (37, 4096, 4096), (2115, 4096, 11008), (4643, 1000, 1024), (300, 264, 320)])
+def test_forced_256_matches_fp32(dev, force256, M, N, K):
+    x, w = _rand(M, K, dev=dev), _rand(N, K, dev=dev, seed=1, scale=0.05)
+    want = x.float() @ w.float().t()
+    first = None
+    for rep in range(4):
+        y = force256.linear(x, w, None, None, 0, False)
+        _check(y, want, K)
+        first = y if first is None else first
+        assert torch.equal(y, first), rep            # deterministic: same schedule, same bits
+
+
+def test_forced_256_epilogues(dev, force256):
+    M, N, K = 700, 1032, 512
+    x, w = _rand(M, K, dev=dev), _rand(N, K, dev=dev, seed=1, scale=0.05)
+    bias, res = _rand(N, dev=dev, seed=2), _rand(M, N, dev=dev, seed=3)
+    lin = x.float() @ w.float().t() + bias.float()
+    y = force256.linear(x, w, bias, res, 1, False)                      # bias + GELU + residual
+    want = torch.nn.functional.gelu(lin).to(torch.bfloat16).float() + res.float()
+    _check(y, want, K)
+    yf = force256.linear(x, w, bias, None, 0, True)                      # fp32 output
+    assert yf.dtype == torch.float32
+    _check(yf, lin, K)
+    pv, pi = force256.linear_argmax_partials(x, w, bias)
+    got = pi.gather(1, pv.argmax(1, keepdim=True))[:, 0].long()
+    assert torch.equal(lin.gather(1, got[:, None]).to(torch.bfloat16), lin.max(1, keepdim=True).values.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 4096), (836, 4096, 1000), (2115, 1024, 264), (264, 11008, 2120)])
+def test_forced_256_kstrided_operands(dev, force256, M, N, K):
+    """dX = dY W (weight K-strided) and dW = dY^T X (both K-strided) on the 8-wave kernel."""
+    from eventgpt_amd.ops import differentiable as diff
+    gy, w, x = _rand(M, N, dev=dev, scale=0.5), _rand(N, K, dev=dev, seed=1, scale=0.05), _rand(M, K, dev=dev, seed=2)
+    for rep in range(3):
+        dx = diff.linear_dgrad(gy, w)
+        _check(dx, gy.float() @ w.float(), N)
+        dw = diff.linear_wgrad(gy, x)
+        _check(dw, gy.float().t() @ x.float(), M)
+
+
+def test_forced_256_identity_exact(dev, force256):
+    """A = I against an asymmetric operand: a wrong row / column / k map gives exact mismatches."""
+    n = 512
+    eye = torch.eye(n, device=dev, dtype=torch.bfloat16)
+    w = (torch.arange(n * 320, device=dev).reshape(320, n) % 251).to(torch.bfloat16)     # [N=320][K=n]
+    assert torch.equal(force256.linear(eye, w, None, None, 0, False), w.t())
+    wt = (torch.arange(n * 264, device=dev).reshape(n, 264) % 241).to(torch.bfloat16)    # [K=n][N=264]
+    assert torch.equal(force256.linear_t(eye, wt, False, True, None, None, 0, False, n), wt)
+    a = (torch.arange(n * 328, device=dev).reshape(n, 328) % 239).to(torch.bfloat16)     # [K=n][M=328]
+    assert torch.equal(force256.linear_t(a, wt, True, True, None, None, 0, True, n), a.float().t() @ wt.float())
+    assert torch.equal(force256.linear_t(a, eye, True, False, None, None, 0, False, n), a.t())
+
+
+def test_auto_dispatch_uses_256_for_large_shapes(dev):
+    from eventgpt_amd.ops import hip
+    x, w = _rand(4643, 4096, dev=dev), _rand(12288, 4096, dev=dev, seed=1, scale=0.05)
+    y_auto = hip.raw.linear(x, w, None, None, 0, False)
+    hip.raw.gemm_enable_256(False)
+    try:
+        y_old = hip.raw.linear(x, w, None, None, 0, False)
+    finally:
+        hip.raw.gemm_enable_256(True)
+    want = x.float() @ w.float().t()
+    _check(y_auto, want, 4096)
+    _check(y_old, want, 4096)
