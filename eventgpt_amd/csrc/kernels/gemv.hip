@@ -85,6 +85,12 @@ struct GemvParams {
 #ifndef EVGPT_GEMV_UNROLL
 #define EVGPT_GEMV_UNROLL 4    // most chunk-iterations whose loads are all issued before the first use
 #endif
+#ifndef EVGPT_GEMV_WFIRST
+#define EVGPT_GEMV_WFIRST 0    // 1: request the PRE weight chunks before the norm's x / norm-weight chunks
+#endif
+#ifndef EVGPT_GEMV_SIMPLE
+#define EVGPT_GEMV_SIMPLE 0    // 1: plain loop unrolled by UNROLL instead of the issue-everything-first shots
+#endif
 #ifndef EVGPT_GEMV_OCC
 #define EVGPT_GEMV_OCC 4       // waves per SIMD a one-row bf16 kernel's register budget must admit
 #endif
@@ -171,19 +177,22 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : (B == 1 ? E
       if (c >= nchunk) dst[i] = u32x4_t{0, 0, 0, 0};
     }
   };
-  if constexpr (P == P_RMSNORM) {
-    if (fast_norm) {
+  auto request_norm_operands = [&]() {
+    if constexpr (P == P_RMSNORM) {
+      if (fast_norm) {
 #pragma unroll
-      for (int i = 0; i < XC; ++i) {
-        const int c = tid + i * GEMV_WAVES * 64;
-        nw[i] = load16(p.norm_w + (c < nchunk ? c : 0) * 8);
-      }
-      if constexpr (!Q) {
+        for (int i = 0; i < XC; ++i) {
+          const int c = tid + i * GEMV_WAVES * 64;
+          nw[i] = load16(p.norm_w + (c < nchunk ? c : 0) * 8);
+        }
+        if constexpr (!Q) {
 #pragma unroll
-        for (int b = 0; b < B; ++b) load_xrow(b, xrow[b]);
+          for (int b = 0; b < B; ++b) load_xrow(b, xrow[b]);
+        }
       }
     }
-  }
+  };
+  if constexpr (!EVGPT_GEMV_WFIRST) request_norm_operands();
   u32x4_t pre[PRE > 0 ? PRE : 1][R];
   float pre_sc[PRE > 0 ? PRE : 1][R];
   if constexpr (STAGE && PRE > 0) {
@@ -202,6 +211,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : (B == 1 ? E
       }
     }
   }
+  if constexpr (EVGPT_GEMV_WFIRST) request_norm_operands();
   if constexpr (P == P_RMSNORM) {
     if (fast_norm) {
 #pragma unroll
@@ -428,6 +438,23 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : (B == 1 ? E
           sc[r] = __builtin_nontemporal_load(sp[r] + (c >> 1));
         }
         consume(wv, sc, c, nullptr);
+      }
+      it_left = 0;
+    } else if constexpr (EVGPT_GEMV_SIMPLE) {
+#pragma unroll(EVGPT_GEMV_UNROLL)
+      for (; c < c_end; c += 64) {
+        u32x4_t wv[R], xg[B];
+        float sc[R];
+        if constexpr (!STAGE) {
+#pragma unroll
+          for (int b = 0; b < B; ++b) xg[b] = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          wv[r] = load_stream16(wp[r] + static_cast<size_t>(c) * 16);
+          sc[r] = 0.f;
+        }
+        consume(wv, sc, c, xg);
       }
       it_left = 0;
     }
