@@ -9,7 +9,13 @@ import torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from eventgpt_amd.models import EventChatConfig, EventChatModel  # noqa: E402
 
+import os  # noqa: E402
+
+from eventgpt_amd.ops import hip  # noqa: E402
+
 lens = [int(a) for a in sys.argv[1:]] or [636, 2115, 4643]
+if os.environ.get("EVGPT_ATTN_WIDE"):      # 0: 64-row attention blocks only, 2: 128-row blocks for every shape
+    hip.raw.attn_enable_wide(int(os.environ["EVGPT_ATTN_WIDE"]))
 dev = torch.device("cuda")
 cfg = EventChatConfig.eventgpt_7b()
 cfg.max_position_embeddings = 8192

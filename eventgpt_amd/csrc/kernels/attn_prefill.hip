@@ -237,6 +237,252 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
   }
 }
 
+// Same computation for long query ranges: one block = 128 query rows, each wave owns TWO 16-row
+// query tiles, so every K fragment (ds_read_b128) and every V^T fragment (two transposing reads)
+// feeds two MFMAs instead of one -- with 16 rows per wave the kernel above reads 32 KB of LDS
+// per wave and key tile for 32 MFMAs and is bound by the LDS pipe.  K / V tiles are staged
+// straight into LDS (buffer_load ... lds, swizzle applied to the per-lane source offset; keys past
+// the end come back as zeros from the descriptor's range check) into a two-tile ring: the loads
+// of tile t+1 are in flight while tile t is computed, and no staging registers are held.
+__device__ __forceinline__ void attn_buffer_to_lds16(const unsigned char* src, int bytes, unsigned char* lds, int voff) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(src), 0, bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (void __attribute__((address_space(3)))*)lds, 16, voff, 0, 0, 0);
+}
+
+constexpr int AW_WAVES = 8;    // 256 query rows per block
+constexpr int AW_STAGES = 4;   // K / V tiles in the LDS ring: three in flight while one is computed
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(AW_WAVES * 64) void attn_prefill_wide_kernel(AttnParams p) {
+  constexpr int CPR = D / 8;
+  constexpr int TILE_BYTES = TK * D * 2;
+  constexpr int NIW = TILE_BYTES / 1024 / AW_WAVES;   // 1 KB staging instructions per wave and tile
+  constexpr int KS = D / 32;
+  constexpr int DT = D / 16;
+  constexpr int QT = 2;
+  constexpr int BR = AW_WAVES * 32;                   // query rows per block
+  static_assert(NIW >= 1, "a tile is at least one staging instruction per wave");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [stage][K | V]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, g = lane >> 4;
+  // grid = (heads, query blocks, batch): consecutive blocks are the same query block of different
+  // heads, so under causal masking the whole grid starts in order of decreasing work
+  const int b = blockIdx.z, h = blockIdx.x;
+  const int hk = h / (p.Hq / p.Hkv);
+  int Sk = p.kv_len ? p.kv_len[b] : p.Sk;
+  Sk = Sk > p.Sk ? p.Sk : (Sk < 0 ? 0 : Sk);
+  const int q_off = p.q_offset_from_len ? (Sk - p.Sq) : p.q_offset;
+  // causal: the blocks with the most keys start first
+  const int qb0 = (CAUSAL ? gridDim.y - 1 - blockIdx.y : blockIdx.y) * BR;
+  const int qw0 = qb0 + wid * 32;            // first query row of this wave
+
+  bf16x8_t qf[QT][KS];
+  int qi[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    qi[qt] = qw0 + qt * 16 + fr;
+    const int qc = qi[qt] < p.Sq ? qi[qt] : p.Sq - 1;
+    const bf16_t* qp = p.q + b * p.q_sb + static_cast<long long>(qc) * p.q_ss + h * p.q_sh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32 + g * 8);
+  }
+
+  const unsigned char* kbase = reinterpret_cast<const unsigned char*>(p.k + b * p.k_sb + hk * p.k_sh);
+  const unsigned char* vbase = reinterpret_cast<const unsigned char*>(p.v + b * p.v_sb + hk * p.v_sh);
+  const long long k_bytes = Sk > 0 ? 2ll * ((Sk - 1) * p.k_ss + D) : 0;
+  const long long v_bytes = Sk > 0 ? 2ll * ((Sk - 1) * p.v_ss + D) : 0;
+  int voff_k[NIW], voff_v[NIW];
+#pragma unroll
+  for (int j = 0; j < NIW; ++j) {
+    const int idx = (wid * NIW + j) * 64 + lane;
+    const int row = idx / CPR, ch = (idx % CPR) ^ swz<D>(row);
+    voff_k[j] = static_cast<int>((row * p.k_ss + ch * 8) * 2);
+    voff_v[j] = static_cast<int>((row * p.v_ss + ch * 8) * 2);
+  }
+  auto stage = [&](int buf, int t) {
+    unsigned char* kd = lds + buf * 2 * TILE_BYTES + wid * NIW * 1024;
+    const long long ka = 2ll * t * TK * p.k_ss, va = 2ll * t * TK * p.v_ss;
+    const int kl = static_cast<int>(k_bytes > ka ? k_bytes - ka : 0), vl = static_cast<int>(v_bytes > va ? v_bytes - va : 0);
+#pragma unroll
+    for (int j = 0; j < NIW; ++j) attn_buffer_to_lds16(kbase + ka, kl, kd + j * 1024, voff_k[j]);
+#pragma unroll
+    for (int j = 0; j < NIW; ++j) attn_buffer_to_lds16(vbase + va, vl, kd + TILE_BYTES + j * 1024, voff_v[j]);
+  };
+
+  int k_end = Sk;
+  if (CAUSAL) k_end = min(Sk, min(qb0 + BR - 1, p.Sq - 1) + q_off + 1);
+  const int ntiles = (k_end + TK - 1) / TK;
+  const bool wave_active = qw0 < p.Sq;
+  const int q_hi = min(qw0 + 31, p.Sq - 1);   // last query row of this wave
+
+  f32x4_t o[QT][DT];
+  float m[QT], l[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m[qt] = -INFINITY; l[qt] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[qt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // The loop is software-pipelined into two phases per key tile,
+  //   S: softmax of tile t (VALU)            M: P·V of tile t, then K·Q^T of tile t+1 (MFMA)
+  // each closed by a barrier, and the two halves of the block (waves 0-3 / 4-7, one of each per
+  // SIMD) run ONE BARRIER APART: while one half is in its MFMA phase the other is in its softmax,
+  // so the SIMD's matrix and vector pipes work at the same time instead of taking turns.
+  f32x4_t st[QT][4];
+  unsigned int pk[QT][4][2];
+  auto qk = [&](const unsigned char* k_lds) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) st[qt][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // k-step outermost: eight independent accumulators between two MFMAs on the same one
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(k_lds + tile_off<D>(n * 16 + fr, ks * 4 + g));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          st[qt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][n], 0, 0, 0);
+      }
+  };
+  auto softmax = [&](int t) {
+    // Online softmax on the RAW scores (the scale is positive, so the maximum commutes with it):
+    // exp2(s * scale - m * scale) is one fma and one v_exp_f32 per score.  The softmax, not the
+    // MFMA, bounds this kernel (16 scores per lane and query tile, 4 cycles per VALU instruction),
+    // so everything avoidable is avoided: keys are masked only in tiles that cross the diagonal
+    // or the end of the keys, and the accumulators are rescaled only when some row's maximum
+    // moved (they live in AGPRs; a rescale moves all of them through VGPRs).
+    const int key0 = t * TK + g * 4;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const int q_lo = qw0 + qt * 16;                     // first query row of the tile (wave-uniform)
+      const int last_key = t * TK + TK - 1;
+      const bool need_mask = last_key > Sk - 1 || (CAUSAL && last_key > q_lo + q_off);
+      if (need_mask) {
+        const int lim = CAUSAL ? min(Sk - 1, qi[qt] + q_off) : Sk - 1;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + n * 16 + r > lim) st[qt][n][r] = -INFINITY;
+      }
+      float mt = fmaxf(fmaxf(st[qt][0][0], st[qt][0][1]), fmaxf(st[qt][0][2], st[qt][0][3]));
+#pragma unroll
+      for (int n = 1; n < 4; ++n)
+        mt = fmaxf(mt, fmaxf(fmaxf(st[qt][n][0], st[qt][n][1]), fmaxf(st[qt][n][2], st[qt][n][3])));
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float mn = fmaxf(m[qt], mt);
+      const float msafe = mn == -INFINITY ? 0.f : mn;
+      if (__builtin_amdgcn_ballot_w64(mn != m[qt]) != 0) {   // some row's maximum moved
+        const float alpha = __builtin_amdgcn_exp2f((m[qt] - msafe) * p.scale_log2e);   // m = -inf -> 0
+        l[qt] *= alpha;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) o[qt][i] *= alpha;
+        m[qt] = mn;
+      }
+      const float ms = msafe * p.scale_log2e;
+      float psum = 0.f;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(fmaf(st[qt][n][r], p.scale_log2e, -ms)); psum += e[r]; }
+        pk[qt][n][0] = pack_bf16x2(e[0], e[1]);
+        pk[qt][n][1] = pack_bf16x2(e[2], e[3]);
+      }
+      l[qt] += psum;
+    }
+  };
+  auto pv = [&](const unsigned char* v_lds) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8_t pf[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        u32x4_t pw = {pk[qt][2 * s2][0], pk[qt][2 * s2][1], pk[qt][2 * s2 + 1][0], pk[qt][2 * s2 + 1][1]};
+        pf[qt] = __builtin_bit_cast(bf16x8_t, pw);
+      }
+      const int q4 = fr >> 2, p4 = fr & 3;
+      const int r0 = s2 * 32 + g * 4 + q4, r1 = r0 + 16;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int ch = dt * 2 + (p4 >> 1);
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4_t __attribute__((address_space(3)))*)(v_lds + tile_off<D>(r0, ch) + 8 * (p4 & 1)));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4_t __attribute__((address_space(3)))*)(v_lds + tile_off<D>(r1, ch) + 8 * (p4 & 1)));
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        const s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf[qt], o[qt][dt], 0, 0, 0);
+      }
+    }
+  };
+  auto fence = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mine = [&](int t) { return wave_active && (!CAUSAL || t * TK <= q_hi + q_off); };
+  auto wait_tile = [&]() {   // all but the youngest tile's loads of this wave have landed
+    if constexpr (2 * NIW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  };
+
+  // Ring of AW_STAGES tiles: while tile t is multiplied, t+1 is being scored, t+2 is landing and
+  // t+3 has just been requested.  Tiles past the last one are requested too: their out-of-range
+  // loads zero-fill a stage nobody reads and keep the count of loads in flight uniform.
+  //   * a stage is re-requested at the start of phase M of tile t for tile t+3: its previous
+  //     content, tile t-1, was last read in phase M of tile t-1, which the late half finishes
+  //     at the barrier the early half passes on entering phase M of tile t;
+  //   * tile t+2 is waited for at the end of phase M of tile t, by every wave before the
+  //     barrier that closes it, and first read in phase M of tile t+1.
+  const bool late = wid >= AW_WAVES / 2;
+#pragma unroll
+  for (int i = 0; i < AW_STAGES - 1; ++i) stage(i, i);
+  wait_tile();                       // tiles 0 and 1
+  fence();
+  if (ntiles > 0 && mine(0)) qk(lds);
+  if (late) fence();
+  for (int t = 0; t < ntiles; ++t) {
+    if (mine(t)) softmax(t);
+    fence();
+    stage((t + AW_STAGES - 1) % AW_STAGES, t + AW_STAGES - 1);
+    if (mine(t)) pv(lds + (t % AW_STAGES) * 2 * TILE_BYTES + TILE_BYTES);
+    if (t + 1 < ntiles && mine(t + 1)) qk(lds + ((t + 1) % AW_STAGES) * 2 * TILE_BYTES);
+    wait_tile();                     // tile t+2
+    fence();
+  }
+  if (!late) fence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // zero fills land before the LDS is handed on
+
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float lt = l[qt];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    if (qi[qt] >= p.Sq) continue;
+    if (p.lse && g == 0)
+      p.lse[(static_cast<long long>(b) * p.Hq + h) * p.Sq + qi[qt]] = lt > 0.f ? m[qt] * p.scale_log2e + log2f(lt) : INFINITY;
+    bf16_t* op = p.o + b * p.o_sb + static_cast<long long>(qi[qt]) * p.o_ss + h * p.o_sh;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      u32x2_t w = {pack_bf16x2(o[qt][dt][0] * inv, o[qt][dt][1] * inv),
+                   pack_bf16x2(o[qt][dt][2] * inv, o[qt][dt][3] * inv)};
+      *reinterpret_cast<u32x2_t*>(op + dt * 16 + g * 4) = w;
+    }
+  }
+}
+
 // Merge the key splits of one query row: thread d owns output column d.
 template <int D>
 __global__ __launch_bounds__(D) void attn_split_combine_kernel(AttnParams p) {
@@ -271,6 +517,9 @@ __global__ __launch_bounds__(D) void attn_split_combine_kernel(AttnParams p) {
   op[d] = f32_to_bf16(l > 0.f ? acc / l : 0.f);
 }
 
+static int g_attn_wide = 1;   // 0 = never, 1 = by shape, 2 = whenever the strides allow (tests, tuning)
+void attn_enable_wide(int mode) { g_attn_wide = mode; }
+
 void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o,
                          const long long* strides /*12: q,k,v,o x (b,s,h)*/, const int* kv_len,
                          int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, int q_offset,
@@ -298,7 +547,34 @@ void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16
     }
     return;
   }
-  dim3 grid((Sq + 63) / 64, Hq, B), block(256);
+  dim3 block(256);
+  // 128-row blocks once there are enough of them to fill the chip (or the sequence is long enough
+  // that their higher arithmetic intensity wins anyway); K / V must allow 16-byte row chunks
+  constexpr int WIDE_ROWS = AW_WAVES * 32;
+  const long long wide_blocks = static_cast<long long>((Sq + WIDE_ROWS - 1) / WIDE_ROWS) * Hq * B;
+  const bool strides_ok = strides[4] % 8 == 0 && strides[7] % 8 == 0 && strides[4] * 2ll * Sk < (1ll << 31) &&
+                          strides[7] * 2ll * Sk < (1ll << 31);
+  if (strides_ok && (g_attn_wide == 2 || (g_attn_wide == 1 && Sq >= 512 && wide_blocks >= 256))) {
+    dim3 wgrid(Hq, (Sq + WIDE_ROWS - 1) / WIDE_ROWS, B), wblock(AW_WAVES * 64);
+    auto go = [&](auto kern, int d) {
+      const int smem = AW_STAGES * 2 * TK * d * 2;
+      static bool attr_set = false;     // one flag per kernel: the lambda is instantiated per kernel type
+      if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, wgrid, wblock, smem, st, p);
+    };
+    if (D == 128) {
+      if (causal) go(attn_prefill_wide_kernel<128, true>, 128);
+      else go(attn_prefill_wide_kernel<128, false>, 128);
+    } else {
+      if (causal) go(attn_prefill_wide_kernel<64, true>, 64);
+      else go(attn_prefill_wide_kernel<64, false>, 64);
+    }
+    return;
+  }
+  dim3 grid((Sq + 63) / 64, Hq, B);
   if (D == 128) {
     if (causal) hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((attn_prefill_kernel<128, false>), grid, block, 0, st, p);

@@ -699,7 +699,32 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
     p.splitk = (K + p.k_per_split - 1) / p.k_per_split;  // drop empty trailing splits
     p.partial = splitk_ws;
   }
-  switch (pick_cfg(M, N)) {
+  const GemmCfg cfg = pick_cfg(M, N);
+  // One workgroup per CU means whole rounds of 256 tiles: a grid of 304 tiles takes as long as
+  // one of 512.  When the last round would be under half full (and there are few rounds for it
+  // to hide in), the 8-wave kernel takes the columns that make whole rounds and the 4-wave
+  // kernel, several blocks per CU, the remaining ones.
+  if (cfg == CFG_256x256 && g_forced_cfg < 0 && p.splitk == 1 && !amax_val) {
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    const long long total = static_cast<long long>(tiles_m) * tiles_n;
+    const int rounds = static_cast<int>(total / 256), rem = static_cast<int>(total % 256);
+    const int cols1 = rounds >= 1 ? (rounds * 256) / tiles_m : 0;     // column tiles of the whole rounds
+    if (rounds >= 1 && rounds <= 2 && rem > 0 && rem < 128 && cols1 >= 1 && cols1 < tiles_n) {
+      const int n1 = cols1 * 256;
+      GemmParams a = p, b = p;
+      a.N = n1;
+      b.N = N - n1;
+      b.W = W + static_cast<size_t>(n1) * ldw;
+      if (C) b.C = C + n1;
+      if (Cf) b.Cf = Cf + n1;
+      if (bias) b.bias = bias + n1;
+      if (res) b.res = res + n1;
+      launch_256<false, false>(a, st);
+      launch_cfg<128, 128, 2, 2, 2>(b, st);
+      return;
+    }
+  }
+  switch (cfg) {
     case CFG_128x128: launch_cfg<128, 128, 2, 2, 2>(p, st); break;
     case CFG_64x128: launch_cfg<64, 128, 2, 2, 3>(p, st); break;
     case CFG_64x64: launch_cfg<64, 64, 2, 2, 4>(p, st); break;

@@ -96,3 +96,21 @@ def test_auto_dispatch_uses_256_for_large_shapes(dev):
     want = x.float() @ w.float().t()
     _check(y_auto, want, 4096)
     _check(y_old, want, 4096)
+
+
+@pytest.mark.parametrize("M,N,K", [(4643, 4096, 512), (4643, 4096 + 264, 256), (2600, 6400, 128)])
+def test_auto_dispatch_column_split_for_partial_rounds(dev, M, N, K):
+    """Tile counts just over whole rounds of CUs (304 = 256 + 48) run as two launches over disjoint
+    column ranges; every epilogue operand is offset with them."""
+    from eventgpt_amd.ops import hip
+    x, w = _rand(M, K, dev=dev), _rand(N, K, dev=dev, seed=1, scale=0.05)
+    bias, res = _rand(N, dev=dev, seed=2), _rand(M, N, dev=dev, seed=3)
+    lin = x.float() @ w.float().t() + bias.float()
+    y = hip.raw.linear(x, w, bias, res, 1, False)
+    want = torch.nn.functional.gelu(lin).to(torch.bfloat16).float() + res.float()
+    _check(y, want, K)
+    yf = hip.raw.linear(x, w, bias, None, 0, True)
+    _check(yf, lin, K)
+    r2 = res.clone()
+    y2 = hip.raw.linear(x, w, None, r2, 0, False)          # plain residual
+    _check(y2, (x.float() @ w.float().t()).to(torch.bfloat16).float() + res.float(), K)
