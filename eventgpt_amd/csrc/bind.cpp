@@ -496,6 +496,19 @@ void fused_adamw(const Tensor& grad, const Tensor& master, const Tensor& exp_avg
     TORCH_CHECK(false, "fused_adamw: bfloat16 or float32 parameters");
 }
 
+// acc[0] += sum(x^2) over a contiguous bf16 / fp32 device tensor (16-byte aligned), deterministic
+void sumsq_accumulate(const Tensor& x, const Tensor& acc) {
+  check_f32(acc, "acc");
+  TORCH_CHECK(x.is_cuda() && x.is_contiguous() && (x.scalar_type() == at::kBFloat16 || x.scalar_type() == at::kFloat),
+              "sumsq_accumulate: contiguous bf16 / fp32 device tensor");
+  TORCH_CHECK(reinterpret_cast<uintptr_t>(x.data_ptr()) % 16 == 0, "sumsq_accumulate: 16-byte aligned input");
+  const int64_t n = x.numel();
+  if (n == 0) return;
+  Tensor part = at::empty({evgpt::sumsq_blocks(n)}, acc.options());
+  evgpt::launch_sumsq(x.data_ptr(), x.scalar_type() == at::kBFloat16, n, part.data_ptr<float>(), acc.data_ptr<float>(),
+                      cur_stream());
+}
+
 // ---- 4-bit codebook weights: `packed` uint8 [N, K/2], `absmax` fp32 [N, K/64], `code` a
 // host bf16 tensor with the 16 codebook entries (read here on the host, so it must not
 // live on the device: these ops run inside graph captures)
@@ -963,6 +976,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("decode_gemv_residual(Tensor w, Tensor xin, Tensor(a!) y) -> ()", &decode_gemv_residual);
   m.def("rmsnorm_bwd(Tensor x, Tensor weight, Tensor grad, float eps, bool want_dw=False) -> (Tensor, Tensor)", &rmsnorm_bwd);
   m.def("swiglu_bwd(Tensor gate_up, Tensor grad) -> Tensor", &swiglu_bwd);
+  m.def("sumsq_accumulate(Tensor x, Tensor(a!) acc) -> ()", &sumsq_accumulate);
   m.def("fused_adamw(Tensor grad, Tensor(a!) master, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor(d!) param_out, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float clip, Tensor? clip_dev=None) -> ()", &fused_adamw);
   m.def("w4_dequant(Tensor packed, Tensor absmax, Tensor code, Tensor(a!)? out=None) -> Tensor", &w4_dequant);
   m.def("gemv_w4_max_batch() -> int", []() { return (int64_t)evgpt::gemv_w4_max_batch(); });

@@ -52,6 +52,9 @@ void launch_fused_adamw_bf16(const bf16_t* grad, float* master, float* m, float*
 void launch_fused_adamw_f32(const float* grad, float* master, float* m, float* v, float* out, long long n,
                             const AdamWArgs& a, hipStream_t st);
 
+int sumsq_blocks(long long n);
+void launch_sumsq(const void* x, bool bf16, long long n, float* part, float* acc, hipStream_t st);
+
 // ---- gemm.hip
 int gemm_argmax_partials(int M, int N);
 void gemm_force_config(int cfg);  // -1 = automatic; for tuning runs

@@ -123,4 +123,52 @@ void launch_fused_adamw_f32(const float* grad, float* master, float* m, float* v
   launch_t<float>(grad, master, m, v, out, n, a, st);
 }
 
+// ---- sum of squares of a gradient shard (global-norm clipping), two deterministic stages:
+// `blocks` partial sums, then one block adds them to acc[0] (fp32; accumulates across buckets).
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const T* __restrict__ x, long long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long long stride = static_cast<long long>(gridDim.x) * 256 * 8;
+  for (long long i0 = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) * 8; i0 < n; i0 += stride) {
+    if (i0 + 8 <= n) {
+      if constexpr (sizeof(T) == 2) {
+        const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(x + i0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float a = bf16lo(v[j]), b = bf16hi(v[j]); s += a * a + b * b; }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(x + i0) + h);
+          s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+      }
+    } else {
+      for (long long i = i0; i < n; ++i) { const float a = ld_as_f32(x + i); s += a * a; }
+    }
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int n, float* __restrict__ acc) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) acc[0] += s;
+}
+
+int sumsq_blocks(long long n) {
+  long long b = (n + 256 * 8 * 4 - 1) / (256 * 8 * 4);   // at least four 16-byte loads per thread
+  return static_cast<int>(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+void launch_sumsq(const void* x, bool bf16, long long n, float* part, float* acc, hipStream_t st) {
+  const int blocks = sumsq_blocks(n);
+  if (bf16) hipLaunchKernelGGL(sumsq_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, static_cast<const bf16_t*>(x), n, part);
+  else hipLaunchKernelGGL(sumsq_partial_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(x), n, part);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, part, blocks, acc);
+}
+
 }  // namespace evgpt

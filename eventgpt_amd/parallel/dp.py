@@ -154,9 +154,22 @@ class ShardedAdamW:
     def _global_sq_norm(self) -> torch.Tensor:
         """Squared global gradient norm as a 0-d fp32 tensor on the shards' device (summed over
         ranks).  Stays on the device with RCCL; a gloo group gets host tensors only."""
-        sq = torch.zeros((), dtype=torch.float32, device=self.buckets[0].grad_shard.device)
-        for b in self.buckets:
-            sq += torch.linalg.vector_norm(b.grad_shard, dtype=torch.float32).square()
+        dev = self.buckets[0].grad_shard.device
+        if dev.type == "cuda":
+            # one streaming pass per bucket (csrc/kernels/optim.hip), accumulated on the device
+            from ..ops import hip
+            acc = torch.zeros(1, dtype=torch.float32, device=dev)
+            for b in self.buckets:
+                g = b.grad_shard
+                if g.dtype in (torch.bfloat16, torch.float32) and g.data_ptr() % 16 == 0:
+                    hip.raw.sumsq_accumulate(g, acc)
+                else:
+                    acc += torch.linalg.vector_norm(g, dtype=torch.float32).square()
+            sq = acc[0]
+        else:
+            sq = torch.zeros((), dtype=torch.float32, device=dev)
+            for b in self.buckets:
+                sq += torch.linalg.vector_norm(b.grad_shard, dtype=torch.float32).square()
         if self.distributed and self.world > 1:
             if dist.get_backend(self.group) == "gloo" and sq.is_cuda:
                 host = sq.cpu()

@@ -98,3 +98,17 @@ def test_device_resident_loaders_yield_the_host_loaders_batches(tmp_path):
     sh = store.DeviceBatchLoader(data, None, 4, dev, shuffle=True, seed=1)
     e1 = torch.cat([b["seq_lens"] for b in sh]); e2 = torch.cat([b["seq_lens"] for b in sh])
     assert sorted(e1.tolist()) == sorted(e2.tolist()) == sorted(data["seq_lens"].tolist())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n", [1, 7, 8, 4099, 1 << 20, (1 << 22) + 5])
+def test_sumsq_accumulate(dtype, n):
+    from eventgpt_amd.ops import hip
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(n)
+    x = (torch.randn(n, device=dev, generator=g) * 3).to(dtype)
+    acc = torch.full((1,), 2.5, device=dev)
+    hip.raw.sumsq_accumulate(x, acc)
+    hip.raw.sumsq_accumulate(x, acc)                       # accumulates; same bits both times
+    want = 2.5 + 2 * float(x.double().pow(2).sum())
+    assert abs(float(acc) - want) < 1e-4 * want
