@@ -42,7 +42,8 @@ from ..models.event_chat import get_spatio_temporal_features
 from ..models.video_llava import VIDEO_PROMPT, load_video_frames
 from ..pipeline.dataset import InstructionDataset, load_questions
 from ..runtime.scheduler import DualModelScheduler
-from ..runtime.spec_decode import AdapterDraftHead, SDStats, SpecDecodeEngine, collect_decode_hidden
+from ..runtime.spec_decode import (AdapterDraftHead, SDStats, SpecDecodeEngine, collect_decode_hidden,
+                                   matches_greedy)
 
 LEVELS = ("L1", "L2", "L3", "L4", "L5", "B1", "L5F")
 PREFILL_LEVELS = ("L1", "L2", "L3", "L4", "L5")
@@ -174,6 +175,17 @@ class E2EBenchmark:
         w = vl.lm_head.weight.data
         self.heads = {k: AdapterDraftHead(a.to(vl.device).to(torch.bfloat16), w) for k, a in adapters.items()}
         self.sched = DualModelScheduler(self.d, self.v)
+        self._sd: Dict[str, SpecDecodeEngine] = {}     # per draft head: keeps its captured rounds across samples
+
+    # -- losslessness -------------------------------------------------------------
+    NEAR_TIE = 0.08      # logit gap below which bf16 kernels of different shapes may order two tokens either way
+
+    def _lossless(self, toks: torch.Tensor, ref: torch.Tensor, v_emb: torch.Tensor) -> Dict:
+        """Token-identical to the verifier's greedy answer -- or first differing at a position where
+        the verifier's own (teacher-forced) logits hold the two candidates closer than bf16 rounding:
+        the verify pass scores several rows with other kernels than the one-row decode step, so such
+        a tie may fall either way.  Scoring resets the verifier engine."""
+        return matches_greedy(self.v, v_emb, toks, ref, self.NEAR_TIE)
 
     # -- one verifier prefill whose state the configs restart from ---------------
     def _verifier_prefill(self, v_emb: torch.Tensor):
@@ -224,7 +236,9 @@ class E2EBenchmark:
                     state = self._snapshot()
                 else:
                     self._restart(state)
-                sd = SpecDecodeEngine(self.v, self.heads[cfg["decode"]], self.gamma)
+                sd = self._sd.get(cfg["decode"])
+                if sd is None:
+                    sd = self._sd[cfg["decode"]] = SpecDecodeEngine(self.v, self.heads[cfg["decode"]], self.gamma)
                 toks, st = sd.run(dh["hidden"], self.max_new, self.eos, cfg["mode"], vh0)
                 extra = 0.0 if cfg["mode"] == "vlm_only" else egpt_decode_ms
                 r = self._result(toks, st, pp["wall_ms"], extra, pp)
@@ -232,8 +246,10 @@ class E2EBenchmark:
                 r = self._hiding(cfg, d_emb, v_emb, dh["hidden"], egpt_decode_ms)
                 state = None            # the verifier was prefilled again by the hiding run
             toks = r.pop("tokens")
-            n = min(toks.shape[0], ref.shape[0])
-            r["lossless"] = bool(torch.equal(toks[:n], ref[:n]))
+            check = self._lossless(toks, ref, v_emb)
+            if not check["exact"]:
+                state = None            # scoring the mismatch reset the verifier
+            r.update(check)
             r["speedup"] = base["total_ms"] / r["sd_total_ms"] if r["sd_total_ms"] > 0 else 0.0
             out["configs"][cfg["name"]] = r
         return out
@@ -301,7 +317,8 @@ def aggregate(samples: List[Dict], configs: List[Dict]) -> Dict[str, Dict]:
              "prefill_ms_mean": _mean(rows, "parallel_prefill_ms"), "decode_ms_mean": _mean(rows, "sd_decode_ms"),
              "total_ms_mean": _mean(rows, "sd_total_ms"), "accept_rate_mean": _mean(rows, "accept_rate"),
              "overlap_ms_mean": _mean(rows, "overlap_ms"), "n_samples": len(rows),
-             "lossless_all": all(r["lossless"] for r in rows)}
+             "lossless_all": all(r["lossless"] for r in rows),
+             "exact_all": all(r.get("exact", r["lossless"]) for r in rows)}
         if any("num_free_tok" in r for r in rows):
             e["num_free_tok_mean"] = _mean(rows, "num_free_tok")
         agg[cfg["name"]] = e
@@ -327,7 +344,8 @@ def write_report(result: Dict, out_dir: str, ts: str) -> Dict[str, str]:
                      "---" if name == "VL baseline" else f"{e['accept_rate_mean']:.1%}",
                      f"{e['speedup_mean']:.2f}x",
                      f"{e['num_free_tok_mean']:.1f}" if "num_free_tok_mean" in e else "---",
-                     "" if name == "VL baseline" else ("yes" if e.get("lossless_all") else "NO")))
+                     "" if name == "VL baseline" else ("yes" if e.get("exact_all", e.get("lossless_all")) else
+                                                     ("near-tie" if e.get("lossless_all") else "NO"))))
     md = [f"# End-to-end wall-clock speculative decoding ({ts})", "",
           f"Samples: {result['n_measured']} measured (+{result['config']['warmup']} warm-up), "
           f"max_new_tokens {result['config']['max_new_tokens']}, gamma {result['config']['gamma']}, "

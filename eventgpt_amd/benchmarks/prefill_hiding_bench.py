@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from ..eval.reports import markdown_table, write_json
+from ..runtime.spec_decode import matches_greedy
 from ..runtime.prefill_hiding import (AlignedPrefillInference, PrefillOnlyInference, PrefillThenVerifyInference,
                                       compute_theoretical_speedup, evaluate_sd_outputs)
 
@@ -74,7 +75,13 @@ class PrefillHidingBenchmark:
         rec: Dict = {"baseline": base_rec}
         for name, r in self.runners.items():
             out = r.generate(d_emb, v_emb, self.eos).as_dict()
-            out["identical_to_baseline"] = out["output_tokens"] == base_rec["tokens"][: len(out["output_tokens"])]
+            # token-identical, or first differing at a near-tie of the verifier's own logits
+            chk = matches_greedy(self.sched.v, v_emb,
+                                 torch.tensor(out["output_tokens"], dtype=torch.long),
+                                 base["tokens"].long().cpu())
+            out["identical_to_baseline"] = bool(chk["lossless"])
+            out["exact_match"] = bool(chk["exact"])
+            out["mismatch_logit_gap"] = chk["mismatch_logit_gap"]
             rec[name] = out
         return rec
 

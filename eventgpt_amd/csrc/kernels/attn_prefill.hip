@@ -127,48 +127,56 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     // ---- S^T tile: 4 sub-tiles of 16 keys
     f32x4_t st[4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      st[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < 4; ++n) st[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < KS; ++ks)      // k-step outermost: four independent accumulators in turn
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(
             k_lds + tile_off<D>(n * 16 + fr, ks * 4 + g));
         st[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[n], 0, 0, 0);
       }
-    }
 
-    // ---- scale, mask, online softmax (lane = one query; 16 keys in registers)
+    // ---- online softmax on the RAW scores (lane = one query; 16 keys in registers).  The scale
+    // is positive, so the maximum commutes with it and exp2(s * scale - m * scale) is one fma and
+    // one v_exp_f32 per score; keys are masked only in tiles that cross the diagonal or the end
+    // of the keys; the accumulators (AGPRs) are rescaled only when some row's maximum moved.
     const int key0 = t * TK + g * 4;
-    const int lim = CAUSAL ? min(Sk - 1, qi + q_off) : Sk - 1;  // last visible key
-    float mt = -INFINITY;
+    const int last_key = t * TK + TK - 1;
+    if (last_key > Sk - 1 || (CAUSAL && last_key > qb0 + wid * 16 + q_off)) {
+      const int lim = CAUSAL ? min(Sk - 1, qi + q_off) : Sk - 1;  // last visible key
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < 4; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key0 + n * 16 + r;
-        const float s = key <= lim ? st[n][r] * p.scale_log2e : -INFINITY;
-        st[n][r] = s;
-        mt = fmaxf(mt, s);
-      }
+        for (int r = 0; r < 4; ++r)
+          if (key0 + n * 16 + r > lim) st[n][r] = -INFINITY;
+    }
+    float mt = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
+#pragma unroll
+    for (int n = 1; n < 4; ++n) mt = fmaxf(mt, fmaxf(fmaxf(st[n][0], st[n][1]), fmaxf(st[n][2], st[n][3])));
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float mn = fmaxf(m, mt);
     const float msafe = mn == -INFINITY ? 0.f : mn;
-    const float alpha = exp2f(m - msafe);  // m = -inf -> 0
+    if (__builtin_amdgcn_ballot_w64(mn != m) != 0) {
+      const float alpha = __builtin_amdgcn_exp2f((m - msafe) * p.scale_log2e);  // m = -inf -> 0
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) o[i] *= alpha;
+      m = mn;
+    }
+    const float ms = msafe * p.scale_log2e;
     float psum = 0.f;
     unsigned int pk[4][2];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       float e[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { e[r] = exp2f(st[n][r] - msafe); psum += e[r]; }
+      for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(fmaf(st[n][r], p.scale_log2e, -ms)); psum += e[r]; }
       pk[n][0] = pack_bf16x2(e[0], e[1]);
       pk[n][1] = pack_bf16x2(e[2], e[3]);
     }
-    l = l * alpha + psum;
-    m = mn;
-#pragma unroll
-    for (int i = 0; i < DT; ++i) o[i] *= alpha;
+    l += psum;
 
     // ---- O^T += V^T · P^T, two k-steps of 32 keys; slot (g, j) <-> key
     //      32s + 4g + j (j < 4) or 32s + 16 + 4g + (j - 4)
@@ -219,13 +227,13 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
         *reinterpret_cast<f32x4_t*>(po + dt * 16 + g * 4) = o[dt];
-      if (g == 0) { p.part_ml[slot * 2] = m; p.part_ml[slot * 2 + 1] = l; }
+      if (g == 0) { p.part_ml[slot * 2] = m * p.scale_log2e; p.part_ml[slot * 2 + 1] = l; }   // m is kept unscaled
     }
     return;
   }
   const float inv = l > 0.f ? 1.f / l : 0.f;
   if (p.lse && g == 0 && qi < p.Sq)
-    p.lse[(static_cast<long long>(b) * p.Hq + h) * p.Sq + qi] = l > 0.f ? m + log2f(l) : INFINITY;
+    p.lse[(static_cast<long long>(b) * p.Hq + h) * p.Sq + qi] = l > 0.f ? m * p.scale_log2e + log2f(l) : INFINITY;
   if (qi < p.Sq) {
     bf16_t* op = p.o + b * p.o_sb + static_cast<long long>(qi) * p.o_ss + h * p.o_sh;
 #pragma unroll

@@ -177,7 +177,9 @@ def evaluate_sd_outputs(results: Sequence[Dict], baseline: Sequence[Dict]) -> Di
     n = min(len(results), len(baseline))
     if n == 0:
         return {"n": 0}
-    same = sum(1 for r, b in zip(results, baseline) if r["output_tokens"] == b["tokens"][:len(r["output_tokens"])])
+    # a runner that compared logits at the first difference says so in `identical_to_baseline`
+    same = sum(1 for r, b in zip(results, baseline)
+               if r.get("identical_to_baseline", r["output_tokens"] == b["tokens"][:len(r["output_tokens"])]))
     sd_ms = sum(r["wall_clock_time"] for r in results[:n]) / n * 1e3
     bl_ms = sum(b["total_ms"] for b in baseline[:n]) / n
     drafted = sum(r["n_drafted"] for r in results[:n])
