@@ -46,7 +46,9 @@ def test_layernorm(dev, rows, H):
     _close(_hip().layernorm(x, w, b, 1e-5), ref.layernorm(x, w, b, 1e-5), 2e-2, 2e-2)
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (2, 1003, 512), (4, 256, 11008), (3, 12288, 4096)])
+# the last four: per-rank shapes of the 7B layer under 8-way tensor parallelism (1408 = 11008 / 8 padded to x64)
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (2, 1003, 512), (4, 256, 11008), (3, 12288, 4096),
+                                   (1, 4096, 512), (1, 4096, 1408), (3, 1536, 4096), (2, 2816, 4096)])
 def test_linear_gemv(dev, M, N, K):
     x, w = _rand(M, K, dev=dev), _rand(N, K, dev=dev, scale=0.02, seed=3)
     if N % 4:
@@ -168,7 +170,8 @@ def test_attention_against_cache(dev, D, Hq, Hkv, Sq, kv, Lmax):
 
 
 # ---- few-row projections: split-K slabs + fused consumers (verify / batched decode)
-@pytest.mark.parametrize("M,N,K", [(6, 4096, 4096), (32, 1536, 512), (2, 4096, 11008), (17, 22016, 4096)])
+@pytest.mark.parametrize("M,N,K", [(6, 4096, 4096), (32, 1536, 512), (2, 4096, 11008), (17, 22016, 4096),
+                                   (32, 4096, 1408), (32, 2816, 4096), (32, 4096, 512)])
 def test_linear_partial_sums_to_linear(dev, M, N, K):
     raw = _hip().raw
     x, w = _rand(M, K, dev=dev, scale=0.5), _rand(N, K, dev=dev, scale=0.05, seed=1)
