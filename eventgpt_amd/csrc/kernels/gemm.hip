@@ -379,13 +379,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 // "sub h" is what the phases consume together: A-sub h = rows {wr*128 + h*64 .. +64} of both wave
 // rows (128 rows), W-sub h = columns {wc*64 + h*32 .. +32} of the four wave columns (128 rows of W).
 //   phase 1: read W-sub0 + A-sub0      MFMA A0 x W0     stage A-sub1 of tile t+1
-//   phase 2: read W-sub1               MFMA A0 x W1
-//   phase 3: read A-sub1               MFMA A1 x W1     stage W-sub0, A-sub0 of tile t+2
+//   phase 2: read W-sub1               MFMA A0 x W1     stage W-sub0 of tile t+2
+//   phase 3: read A-sub1               MFMA A1 x W1     stage A-sub0 of tile t+2
 //   phase 4: (operands in registers)   MFMA A1 x W0     stage W-sub1 of tile t+2, then wait
 // Ordering rules this schedule is built on (P = phase counter over the whole loop):
-//   * an image read in phase P is re-staged in phase P+2 or later: the reading wave row may
-//     be the late one, whose reads have returned only when it reaches the first barrier of
-//     its phase P+1, which is the second barrier of the early row's phase P+1;
+//   * an image read in phase P may be re-staged from phase P+1 on: every wave waits for its
+//     LDS reads (lgkmcnt) before the first barrier of the phase it issued them in, and the
+//     late wave row passes that barrier as the second barrier of the early row's phase P,
+//     which the early row has behind it when it issues in phase P+1;
 //   * staged data is read one phase after the wait that retires it: every wave waits
 //     (counted vmcnt: the three youngest images stay in flight) before the first barrier of
 //     its phase 4, and the reads of the next tile start after that phase's second barrier,
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   // workgroup barrier that neither the compiler's passes nor its scheduler move code across
   auto fence = [&]() {
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads have returned
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -529,12 +530,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     fence();
     // phase 2
     read_w(buf, 1);
+    stage(2, kt + 2);
     fence();
     mma(0, 1);
     fence();
     // phase 3
     read_a(buf, 1);
-    stage(2, kt + 2);
     stage(0, kt + 2);
     fence();
     mma(1, 1);
