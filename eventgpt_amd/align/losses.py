@@ -39,11 +39,57 @@ def masked_mean(values: torch.Tensor, mask: Optional[torch.Tensor]) -> torch.Ten
     return (values * m).sum() / m.sum().clamp_min(1.0)
 
 
+class _RowPairLoss(torch.autograd.Function):
+    """``(masked MSE, masked mean cosine)`` of ``pred`` vs ``target`` on the GPU in one pass each way.
+
+    Both are functions of four sums per row -- ``p.t, |p|^2, |t|^2, |p-t|^2`` -- which one kernel
+    produces (``row_stats``); the gradient is ``A_r (p - t) + B_r t + C_r p`` with per-row
+    coefficients, which one kernel applies (``row_affine_grad``).  Autograd through the tensor
+    expressions above writes and re-reads about a dozen full-size temporaries, a third of an
+    L1 adapter's training step.  ``target`` gets no gradient (it is data)."""
+
+    EPS = 1e-12      # F.normalize's clamp on the norms
+
+    @staticmethod
+    def forward(ctx, pred, target, mask):
+        from ..ops import hip
+        h = pred.shape[-1]
+        st = hip.raw.row_stats(pred, target)                       # [rows, 4]
+        m = torch.ones(st.shape[0], device=st.device) if mask is None else mask.reshape(-1).to(torch.float32)
+        n_valid = m.sum().clamp_min(1.0)
+        dot, na, nb, se = st.unbind(1)
+        pn, tn = na.sqrt().clamp_min(_RowPairLoss.EPS), nb.sqrt().clamp_min(_RowPairLoss.EPS)
+        cos = dot / (pn * tn)
+        ctx.save_for_backward(pred, target, m, n_valid, pn, tn, cos)
+        ctx.h = h
+        return (se * m).sum() / (n_valid * h), (cos * m).sum() / n_valid
+
+    @staticmethod
+    def backward(ctx, g_mse, g_cos):
+        from ..ops import hip
+        pred, target, m, n_valid, pn, tn, cos = ctx.saved_tensors
+        w = m / n_valid
+        a = g_mse * 2.0 * w / ctx.h                                # d mse / d p = 2 (p - t) m / (n H)
+        b = g_cos * w / (pn * tn)                                  # d cos / d p = t / (|p||t|) - cos p / |p|^2
+        c = -g_cos * w * cos / (pn * pn)
+        coef = torch.stack([a, b, c], dim=1).contiguous().float()
+        return hip.raw.row_affine_grad(pred, target, coef), None, None
+
+
+def _fused_pair_ok(pred: torch.Tensor, target: torch.Tensor) -> bool:
+    return (pred.is_cuda and target.is_cuda and pred.dtype == target.dtype and pred.shape == target.shape
+            and pred.dtype in (torch.float32, torch.bfloat16) and pred.shape[-1] % 8 == 0
+            and pred.is_contiguous() and target.is_contiguous() and not target.requires_grad)
+
+
 def alignment_losses(pred: torch.Tensor, target: torch.Tensor,
                      mask: Optional[torch.Tensor] = None,
                      prediction_weight: float = 0.0) -> Dict[str, torch.Tensor]:
-    mse = masked_mse(pred, target, mask)
-    cos_sim = masked_mean(cosine_per_position(pred, target), mask)
+    if _fused_pair_ok(pred, target):
+        mse, cos_sim = _RowPairLoss.apply(pred, target, mask)
+    else:
+        mse = masked_mse(pred, target, mask)
+        cos_sim = masked_mean(cosine_per_position(pred, target), mask)
     cos_loss = 1.0 - cos_sim
     align = mse + 0.5 * cos_loss
     out = {"mse_loss": mse, "cos_loss": cos_loss, "cos_sim": cos_sim}

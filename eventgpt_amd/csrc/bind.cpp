@@ -259,6 +259,43 @@ std::tuple<Tensor, Tensor> row_metrics(const Tensor& a, const Tensor& b, double 
   return {c, m};
 }
 
+// [rows, 4] = (dot, |a|^2, |b|^2, |a-b|^2) per row of two equally shaped tensors
+Tensor row_stats(const Tensor& a, const Tensor& b) {
+  TORCH_CHECK(a.is_cuda() && b.is_cuda() && a.is_contiguous() && b.is_contiguous() &&
+              a.sizes() == b.sizes() && a.scalar_type() == b.scalar_type(),
+              "row_stats: two contiguous GPU tensors of one shape and dtype");
+  const int64_t H = a.size(-1), rows = H ? a.numel() / H : 0;
+  Tensor s = at::zeros({rows, 4}, a.options().dtype(at::kFloat));
+  if (rows == 0) return s;
+  if (a.scalar_type() == at::kFloat) {
+    TORCH_CHECK(H % 4 == 0, "row_stats: row length must be a multiple of 4 (fp32)");
+    evgpt::launch_row_metrics_f32(a.data_ptr<float>(), b.data_ptr<float>(), nullptr, nullptr, rows, (int)H, 0.f,
+                                  cur_stream(), s.data_ptr<float>());
+  } else if (a.scalar_type() == at::kBFloat16) {
+    TORCH_CHECK(H % 8 == 0, "row_stats: row length must be a multiple of 8 (bf16)");
+    evgpt::launch_row_metrics_bf16(bptr(a), bptr(b), nullptr, nullptr, rows, (int)H, 0.f, cur_stream(),
+                                   s.data_ptr<float>());
+  } else {
+    TORCH_CHECK(false, "row_stats: float32 or bfloat16 only");
+  }
+  return s;
+}
+
+// grad[r] = A_r (p_r - t_r) + B_r t_r + C_r p_r with coef [rows, 3] fp32
+Tensor row_affine_grad(const Tensor& p, const Tensor& t, const Tensor& coef) {
+  check_f32(coef, "coef");
+  TORCH_CHECK(p.is_cuda() && t.is_cuda() && p.is_contiguous() && t.is_contiguous() && p.sizes() == t.sizes() &&
+              p.scalar_type() == t.scalar_type(), "row_affine_grad: two contiguous GPU tensors of one shape and dtype");
+  const int64_t H = p.size(-1), rows = H ? p.numel() / H : 0;
+  const bool bf = p.scalar_type() == at::kBFloat16;
+  TORCH_CHECK(bf || p.scalar_type() == at::kFloat, "row_affine_grad: float32 or bfloat16 only");
+  TORCH_CHECK(H % (bf ? 8 : 4) == 0 && coef.numel() == rows * 3, "row_affine_grad: row length / coefficient count");
+  Tensor g = at::empty_like(p);
+  if (rows) evgpt::launch_row_affine_grad(p.data_ptr(), t.data_ptr(), coef.data_ptr<float>(), g.data_ptr(), rows, (int)H, bf,
+                                          cur_stream());
+  return g;
+}
+
 Tensor swiglu(const Tensor& gate_up) {
   check_bf16(gate_up, "gate_up");
   const int64_t I2 = gate_up.size(-1);
@@ -971,6 +1008,8 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("st_pool(Tensor f, int n_temporal) -> Tensor", &st_pool);
   m.def("argmax_rows(Tensor x) -> Tensor", &argmax_rows);
   m.def("row_metrics(Tensor a, Tensor b, float eps) -> (Tensor, Tensor)", &row_metrics);
+  m.def("row_stats(Tensor a, Tensor b) -> Tensor", &row_stats);
+  m.def("row_affine_grad(Tensor p, Tensor t, Tensor coef) -> Tensor", &row_affine_grad);
   m.def("decode_qkv(Tensor x, Tensor norm_w, Tensor w_qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos, float eps, int Hq, int Hkv, int D, bool one_seq=False) -> ()", &decode_qkv);
   m.def("decode_attn(Tensor q, Tensor k_cache, Tensor v_cache, Tensor(a!) out, Tensor(b!) part_o, Tensor(c!) part_ml, Tensor pos, int nsplit, float scale) -> ()", &decode_attn);
   m.def("decode_gemv_residual(Tensor w, Tensor xin, Tensor(a!) y) -> ()", &decode_gemv_residual);

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void row_metrics_kernel(const T* __restrict__ 
                                                           const T* __restrict__ b,
                                                           float* __restrict__ cos_out,
                                                           float* __restrict__ mse_out, long long rows,
-                                                          int H, float eps) {
+                                                          int H, float eps, float* __restrict__ stats) {
   const long long r = blockIdx.x * 4ll + (threadIdx.x >> 6);
   if (r >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -217,20 +217,71 @@ __global__ __launch_bounds__(256) void row_metrics_kernel(const T* __restrict__ 
   }
   dot = wave_sum(dot); na = wave_sum(na); nb = wave_sum(nb); se = wave_sum(se);
   if (lane == 0) {
+    if (stats) {   // the raw sums: a loss function's backward needs them
+      *reinterpret_cast<f32x4_t*>(stats + r * 4) = f32x4_t{dot, na, nb, se};
+      return;
+    }
     cos_out[r] = dot / (fmaxf(sqrtf(na), eps) * fmaxf(sqrtf(nb), eps));
     mse_out[r] = se / static_cast<float>(H);
   }
 }
 
+// Gradient of a loss that is a function of the per-row sums above (masked MSE + cosine):
+//   grad[r][i] = A_r (p_i - t_i) + B_r t_i + C_r p_i,   coef[r] = {A_r, B_r, C_r}
+// in one pass over the pair (autograd through normalise / multiply / reduce writes and re-reads
+// a dozen full-size temporaries).
+template <typename T>
+__global__ __launch_bounds__(256) void row_affine_grad_kernel(const T* __restrict__ p, const T* __restrict__ t,
+                                                              const float* __restrict__ coef, T* __restrict__ grad,
+                                                              long long rows, int H) {
+  constexpr int EPV = 16 / sizeof(T);
+  const int cpr = H / EPV;
+  const long long total = rows * cpr;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += gridDim.x * 256ll) {
+    const long long r = idx / cpr;
+    const float A = coef[r * 3], B = coef[r * 3 + 1], C = coef[r * 3 + 2];
+    if constexpr (sizeof(T) == 4) {
+      const f32x4_t vp = reinterpret_cast<const f32x4_t*>(p)[idx], vt = reinterpret_cast<const f32x4_t*>(t)[idx];
+      f32x4_t g;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] = A * (vp[i] - vt[i]) + B * vt[i] + C * vp[i];
+      reinterpret_cast<f32x4_t*>(grad)[idx] = g;
+    } else {
+      const u32x4_t vp = reinterpret_cast<const u32x4_t*>(p)[idx], vt = reinterpret_cast<const u32x4_t*>(t)[idx];
+      u32x4_t g;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float pl = bf16lo(vp[i]), ph = bf16hi(vp[i]), tl = bf16lo(vt[i]), th = bf16hi(vt[i]);
+        g[i] = pack_bf16x2(A * (pl - tl) + B * tl + C * pl, A * (ph - th) + B * th + C * ph);
+      }
+      reinterpret_cast<u32x4_t*>(grad)[idx] = g;
+    }
+  }
+}
+
+void launch_row_affine_grad(const void* p, const void* t, const float* coef, void* grad, long long rows, int H,
+                            bool bf16, hipStream_t st) {
+  const long long total = rows * (H / (bf16 ? 8 : 4));
+  int blocks = static_cast<int>((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) return;
+  if (bf16)
+    hipLaunchKernelGGL(row_affine_grad_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, static_cast<const bf16_t*>(p),
+                       static_cast<const bf16_t*>(t), coef, static_cast<bf16_t*>(grad), rows, H);
+  else
+    hipLaunchKernelGGL(row_affine_grad_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(p),
+                       static_cast<const float*>(t), coef, static_cast<float*>(grad), rows, H);
+}
+
 void launch_row_metrics_f32(const float* a, const float* b, float* cos_out, float* mse_out,
-                            long long rows, int H, float eps, hipStream_t st) {
+                            long long rows, int H, float eps, hipStream_t st, float* stats) {
   hipLaunchKernelGGL(row_metrics_kernel<float>, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256),
-                     0, st, a, b, cos_out, mse_out, rows, H, eps);
+                     0, st, a, b, cos_out, mse_out, rows, H, eps, stats);
 }
 void launch_row_metrics_bf16(const bf16_t* a, const bf16_t* b, float* cos_out, float* mse_out,
-                             long long rows, int H, float eps, hipStream_t st) {
+                             long long rows, int H, float eps, hipStream_t st, float* stats) {
   hipLaunchKernelGGL(row_metrics_kernel<bf16_t>, dim3(static_cast<unsigned>((rows + 3) / 4)),
-                     dim3(256), 0, st, a, b, cos_out, mse_out, rows, H, eps);
+                     dim3(256), 0, st, a, b, cos_out, mse_out, rows, H, eps, stats);
 }
 
 void launch_reduce_residual_norm(const float* partial, int nslab, int M, int N, const bf16_t* res,

@@ -112,3 +112,40 @@ def test_sumsq_accumulate(dtype, n):
     hip.raw.sumsq_accumulate(x, acc)                       # accumulates; same bits both times
     want = 2.5 + 2 * float(x.double().pow(2).sum())
     assert abs(float(acc) - want) < 1e-4 * want
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("masked", [False, True])
+def test_fused_alignment_loss_matches_tensor_expressions(dtype, masked):
+    """Masked MSE + cosine alignment loss: the two-kernel Function vs autograd through the tensor
+    expressions (values of every reported loss, and the gradient of the total)."""
+    from eventgpt_amd.align import losses as L
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(4)
+    B, S, H = 6, 11, 512
+    pred = torch.randn(B, S, H, device=dev, generator=g).to(dtype).requires_grad_(True)
+    target = (torch.randn(B, S, H, device=dev, generator=g) * 1.5).to(dtype)
+    mask = (torch.rand(B, S, device=dev, generator=g) > 0.3).float() if masked else None
+    for w in (0.0, 0.3):
+        out = L.alignment_losses(pred, target, mask, prediction_weight=w)
+        assert type(out["mse_loss"].grad_fn).__name__ == "_RowPairLossBackward"
+        out["total_loss"].backward()
+        got_grad, pred.grad = pred.grad.clone(), None
+        p32 = pred.detach().float().requires_grad_(True)
+        t32 = target.float()
+        mse = L.masked_mse(p32, t32, mask)
+        cos = L.masked_mean(L.cosine_per_position(p32, t32), mask)
+        align = mse + 0.5 * (1 - cos)
+        if w > 0:
+            pl = L.masked_mse(p32[:, :-1], t32[:, 1:], None if mask is None else mask[:, 1:])
+            total = (1 - w) * align + w * pl
+        else:
+            total = align
+        total.backward()
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        assert abs(float(out["mse_loss"]) - float(mse)) < tol * float(mse)
+        assert abs(float(out["cos_sim"]) - float(cos)) < max(tol, 1e-5)
+        assert abs(float(out["total_loss"]) - float(total)) < tol * float(total)
+        scale = float(p32.grad.abs().max())
+        assert torch.allclose(got_grad.float(), p32.grad, atol=(1e-6 if dtype == torch.float32 else 1e-2) * scale + 1e-9,
+                              rtol=1e-4 if dtype == torch.float32 else 2e-2)
