@@ -32,8 +32,12 @@ def test_prefill_hidden_matches_module(model, dev):
     # module path output is post-norm; compare pre-norm state of the last layer
     from eventgpt_amd import ops
     hn = ops.rmsnorm(h, model.model.norm.weight, model.config.rms_norm_eps)
-    err = (hn.float() - ref.last_hidden_state[0].float()).abs().max().item()
-    assert err < 0.15, err
+    want = ref.last_hidden_state[0].float().detach()
+    err = (hn.float() - want).abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(hn.float(), want, dim=-1)
+    # two bf16 implementations of three layers: every row points the same way, and the worst
+    # element is off by a few bf16 ulps of the row's largest value
+    assert float(cos.min()) > 0.9995 and err < 0.03 * float(want.abs().max()), (float(cos.min()), err)
     # cache contents match the module path's cache
     k_mod = ref.past_key_values[1][0][0]     # [H, S, D]
     k_eng = eng.layers[1].k_cache[0, :, :S]
@@ -95,11 +99,11 @@ def test_teacher_forced_logits_match_cpu_fp32(model, dev):
 
 @pytest.mark.timeout(600)
 def test_7b_geometry_two_layers_logits(dev):
-    """EventGPT-7B layer geometry (4096 / 11008 / 32 heads of 128 / vocab 32000), two layers: the
+    """EventGPT-7B layer geometry (4096 / 11008 / 32 heads of 128 / vocab 32003), two layers: the
     shapes the production kernels are tuned for (GEMV K-split, 128-wide attention, lm_head argmax
     partials), which the 512-wide test models never reach.  Engine (graph replay) vs module path
     (bf16) vs CPU fp32, teacher-forced along the engine's own greedy path, at a 636-token prompt."""
-    cfg = EventChatConfig(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=2,
+    cfg = EventChatConfig(vocab_size=32003, hidden_size=4096, intermediate_size=11008, num_hidden_layers=2,
                           num_attention_heads=32, max_position_embeddings=4096, torch_dtype="bfloat16")
     m = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=5)
     g = torch.Generator(device=dev).manual_seed(1)
@@ -327,7 +331,7 @@ def test_long_prompt_prefill_and_decode(dev):
     ref = m.model(inputs_embeds=emb[None], use_cache=True)
     from eventgpt_amd import ops
     hn = ops.rmsnorm(h, m.model.norm.weight, cfg.rms_norm_eps).float()
-    want = ref.last_hidden_state[0].float()
+    want = ref.last_hidden_state[0].float().detach()
     cos = torch.nn.functional.cosine_similarity(hn, want, dim=-1)
     assert cos.min().item() > 0.995 and (hn - want).abs().max().item() < 0.25
     k_mod = ref.past_key_values[1][0][0]
