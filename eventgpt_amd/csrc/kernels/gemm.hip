@@ -636,7 +636,10 @@ static bool use_256(int M, int N) {
   return g_use_256 && M >= 1024 && t >= 128;
 }
 
-static GemmCfg pick_cfg(int M, int N) {
+static int g_forced_splitk = 0;
+
+// K = 0: the caller cannot split K (argmax partials, K-strided operands)
+static GemmCfg pick_cfg(int M, int N, int K = 0) {
   if (g_forced_cfg >= 0) return static_cast<GemmCfg>(g_forced_cfg);
   auto tiles = [&](int bm, int bn) {
     return static_cast<long long>((M + bm - 1) / bm) * ((N + bn - 1) / bn);
@@ -644,6 +647,14 @@ static GemmCfg pick_cfg(int M, int N) {
   // thresholds from benchmarks/bench_gemm.py on MI355X
   if (M <= 32) return tiles(32, 128) >= 256 ? CFG_32x128 : CFG_32x64;
   if (use_256(M, N)) return CFG_256x256;
+  // Narrow outputs over a long contraction (a few hundred rows into 4096 columns over 11008, the
+  // ViT's 4096 -> 1024 projection): the larger tile, its grid filled by splitting K (gemm_splitk)
+  // instead of by shrinking the tile.  636 x 4096 x 11008: 128x128 with 3 splits 806 TFLOP/s,
+  // 64x128 unsplit 608; 577 x 1024 x 4096: 64x128 with 3 splits 237, 32x64 unsplit 184.
+  if (M <= 1024 && g_forced_splitk == 0) {
+    if (K >= 8192 && tiles(128, 128) >= 96 && tiles(128, 128) < 256) return CFG_128x128;
+    if (K >= 4096 && tiles(64, 128) >= 48 && tiles(64, 128) < 128) return CFG_64x128;
+  }
   if (tiles(128, 128) >= 384) return CFG_128x128;
   if (tiles(64, 128) >= 300) return CFG_64x128;
   if (tiles(64, 64) >= 300) return CFG_64x64;
@@ -655,7 +666,6 @@ static long long cfg_tiles(GemmCfg c, int M, int N) {
   return static_cast<long long>((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]);
 }
 
-static int g_forced_splitk = 0;
 void gemm_force_splitk(int sk) { g_forced_splitk = sk; }
 
 // Split K when the output grid alone cannot fill the chip and K is long enough
@@ -664,7 +674,15 @@ int gemm_splitk(int M, int N, int K) {
   if (g_forced_splitk > 0) return (K / 64) >= g_forced_splitk ? g_forced_splitk : 1;
   // measured (benchmarks/bench_gemm.py): the extra reduce pass only pays for
   // weight-streaming shapes with a handful of rows (batched decode, verify)
-  if (M > 32) return 1;
+  if (M > 32) {
+    if (M > 1024) return 1;
+    const GemmCfg cfg = pick_cfg(M, N, K);
+    const long long tl = cfg_tiles(cfg, M, N);
+    int s = 1;   // fill the co-resident slots (2 blocks of 128x128, 3 of 64x128 per CU)
+    if (cfg == CFG_128x128 && K >= 8192 && tl >= 96 && tl < 256) s = static_cast<int>(512 / tl);
+    else if (cfg == CFG_64x128 && K >= 4096 && tl >= 48 && tl < 128) s = static_cast<int>(256 / tl);
+    return s < 1 ? 1 : (s > 4 ? 4 : s);
+  }
   const long long t = cfg_tiles(pick_cfg(M, N), M, N);
   if (t >= 256) return 1;
   // one block per CU.  Twice as many splits stream the weights 5-20 % faster in
@@ -700,7 +718,7 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
     p.splitk = (K + p.k_per_split - 1) / p.k_per_split;  // drop empty trailing splits
     p.partial = splitk_ws;
   }
-  const GemmCfg cfg = pick_cfg(M, N);
+  const GemmCfg cfg = pick_cfg(M, N, (splitk_ws && !amax_val) ? K : 0);
   // One workgroup per CU means whole rounds of 256 tiles: a grid of 304 tiles takes as long as
   // one of 512.  When the last round would be under half full (and there are few rounds for it
   // to hide in), the 8-wave kernel takes the columns that make whole rounds and the 4-wave
