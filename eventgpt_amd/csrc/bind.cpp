@@ -154,9 +154,13 @@ Tensor linear_t(const Tensor& a, const Tensor& w, bool a_t, bool w_t, const c10:
   if (res.has_value()) { check_bf16(*res, "residual"); TORCH_CHECK(res->numel() == M * N); }
   Tensor y = at::empty({M, N}, a.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
   if (M == 0 || N == 0) return y;
+  const int sk = evgpt::gemm_splitk_t((int)M, (int)N, (int)K);
+  Tensor ws;
+  if (sk > 1) ws = at::empty({sk * M * N}, a.options().dtype(at::kFloat));
   evgpt::launch_gemm_bf16_t(bptr(a), bptr(w), out_f32 ? nullptr : bptr_mut(y), out_f32 ? y.data_ptr<float>() : nullptr,
                             bptr_opt(bias), bptr_opt(res), (int)M, (int)N, (int)K, (int)a.size(1), (int)w.size(1),
-                            (int)N, (int)act, a_t, w_t, (int)ka_rows, (int)kw_rows, cur_stream());
+                            (int)N, (int)act, a_t, w_t, (int)ka_rows, (int)kw_rows, cur_stream(),
+                            sk > 1 ? ws.data_ptr<float>() : nullptr, sk);
   return y;
 }
 

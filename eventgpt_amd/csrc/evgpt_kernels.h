@@ -64,9 +64,10 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
                       const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
                       float* amax_val, int* amax_idx, float* splitk_ws, int splitk,
                       hipStream_t st);
+int gemm_splitk_t(int M, int N, int K);   // K splits for launch_gemm_bf16_t (1 = none)
 void launch_gemm_bf16_t(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,
                         const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
-                        bool a_t, bool w_t, int ka_rows, int kw_rows, hipStream_t st);
+                        bool a_t, bool w_t, int ka_rows, int kw_rows, hipStream_t st, float* splitk_ws = nullptr, int splitk = 1);
 int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M, int N, int K,
                         int lda, int ldw, hipStream_t st);
 int gemm_splitk(int M, int N, int K);   // planned split count (1 = none); ws = splitk*M*N floats

@@ -633,7 +633,10 @@ void gemm_force_config(int cfg) { g_forced_cfg = cfg; }
 // 948 and 2885 x 1024 x 4096, 48 tiles, 282 vs 567).
 static bool use_256(int M, int N) {
   const long long t = static_cast<long long>((M + 255) / 256) * ((N + 255) / 256);
-  return g_use_256 && M >= 1024 && t >= 128;
+  // 768..1023 rows are three or four row tiles (up to a quarter of the last one empty): still ahead
+  // once the tiles come near one round (836 x 12288 x 4096: 914 vs 833 TFLOP/s; K-strided W,
+  // 836 x 11008 x 4096: 686 vs 582), behind for 64 tiles (836 x 4096: 338 vs 700)
+  return g_use_256 && ((M >= 1024 && t >= 128) || (M >= 768 && t >= 160));
 }
 
 static int g_forced_splitk = 0;
@@ -759,6 +762,16 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
   }
 }
 
+// dX = dY W of a few hundred tokens is a narrow output (tokens x 4096) over a contraction of
+// 12288 or 22016: the 128 x 128 tile with K split over the co-resident slots, as in pick_cfg.
+int gemm_splitk_t(int M, int N, int K) {
+  if (g_forced_splitk > 0) return (K / 64) >= g_forced_splitk ? g_forced_splitk : 1;
+  const long long t = static_cast<long long>((M + 127) / 128) * ((N + 127) / 128);
+  if (M > 1024 || K < 8192 || t < 96 || t >= 256 || g_forced_cfg >= 0) return 1;
+  const int s = static_cast<int>(512 / t);
+  return s < 1 ? 1 : (s > 4 ? 4 : s);
+}
+
 // C[M,N] = opA · opW^T with K-strided operands: a_t -> A is stored [K][M] (lda = its row
 // stride), w_t -> W is stored [K][N].  Used by the backward products of a linear layer.
 // M (if a_t) and N (if w_t) must be multiples of 8 and >= 8; K a multiple of 64; ka_rows /
@@ -769,7 +782,8 @@ static void launch_t(const GemmParams& p, hipStream_t st) {
     return static_cast<long long>((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
   };
   const bool cols_ok = (!AT || p.M % 8 == 0) && (!BT || p.N % 8 == 0);
-  if ((g_forced_cfg == CFG_256x256 || (g_forced_cfg < 0 && use_256(p.M, p.N))) && cols_ok) launch_256<AT, BT>(p, st);
+  if (p.splitk > 1) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
+  else if ((g_forced_cfg == CFG_256x256 || (g_forced_cfg < 0 && use_256(p.M, p.N))) && cols_ok) launch_256<AT, BT>(p, st);
   else if (tiles(128, 128) >= 384) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
   else if (tiles(64, 128) >= 300) launch_cfg<64, 128, 2, 2, 3, AT, BT>(p, st);
   else launch_cfg<64, 64, 2, 2, 4, AT, BT>(p, st);
@@ -777,13 +791,25 @@ static void launch_t(const GemmParams& p, hipStream_t st) {
 
 void launch_gemm_bf16_t(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,
                         const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
-                        bool a_t, bool w_t, int ka_rows, int kw_rows, hipStream_t st) {
+                        bool a_t, bool w_t, int ka_rows, int kw_rows, hipStream_t st, float* splitk_ws, int splitk) {
   GemmParams p{A, W, C, bias, res, Cf, M, N, K, lda, ldw, ldc, act, nullptr, nullptr, 1, K, nullptr, 0,
                ka_rows, kw_rows};
+  if (splitk > 1 && splitk_ws) {
+    const int ksteps = K / 64;
+    p.k_per_split = ((ksteps + splitk - 1) / splitk) * 64;
+    p.splitk = (K + p.k_per_split - 1) / p.k_per_split;
+    p.partial = splitk_ws;
+  }
   if (a_t && w_t) launch_t<true, true>(p, st);
   else if (a_t) launch_t<true, false>(p, st);
   else if (w_t) launch_t<false, true>(p, st);
   else launch_t<false, false>(p, st);
+  if (p.splitk > 1) {
+    const long long quads = (static_cast<long long>(M) * N + 3) / 4;
+    int blocks = static_cast<int>((quads + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+  }
 }
 
 // Projection that stops at the fp32 split-K slabs partial[nslab][M][N]; returns

@@ -23,7 +23,8 @@ def _close(a, b, atol, rtol):
 
 
 @pytest.mark.parametrize("M,N,K", [(840, 4096, 4096), (636, 11008, 4096), (64, 4096, 1024), (200, 16, 4096),
-                                   (130, 4096, 16), (577, 1000, 1024), (2115, 4096, 11008)])
+                                   (130, 4096, 16), (577, 1000, 1024), (2115, 4096, 11008),
+                                   (836, 12288, 4096), (636, 22016, 4096)])   # dgrad splits its long contraction
 def test_dgrad_and_wgrad_match_fp32(dev, M, N, K):
     """dX = dY W and dW = dY^T X through the K-strided operand paths (any M, padded contraction)."""
     from eventgpt_amd.ops import differentiable as diff
