@@ -11,6 +11,9 @@ from eventgpt_amd.models import EventChatConfig, EventChatModel  # noqa: E402
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda")
+if __import__("os").environ.get("EVGPT_ATTN_WIDE"):      # 0: 64-row attention blocks only (A/B runs)
+    from eventgpt_amd.ops import hip
+    hip.raw.attn_enable_wide(int(__import__("os").environ["EVGPT_ATTN_WIDE"]))
 cfg = EventChatConfig.eventgpt_7b(vocab_size=32003)
 cfg.num_hidden_layers = 1                      # the decoder is not used here
 model = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=0)

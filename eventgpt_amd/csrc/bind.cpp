@@ -789,6 +789,7 @@ std::tuple<Tensor, Tensor> linear_argmax_partials(const Tensor& x, const Tensor&
 void gemm_force_config(int64_t cfg) { evgpt::gemm_force_config((int)cfg); }
 void gemm_enable_256(bool on) { evgpt::gemm_enable_256(on); }
 void attn_enable_wide(int64_t mode) { evgpt::attn_enable_wide((int)mode); }
+void attn_wide4_min_rows(int64_t rows) { evgpt::attn_wide4_min_rows((int)rows); }
 void gemm_force_splitk(int64_t sk) { evgpt::gemm_force_splitk((int)sk); }
 void gemv_force_ks(int64_t ks) { evgpt::gemv_force_ks((int)ks); }
 
@@ -1039,6 +1040,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("gemm_force_config(int cfg) -> ()", &gemm_force_config);
   m.def("gemm_enable_256(bool on) -> ()", &gemm_enable_256);
   m.def("attn_enable_wide(int mode) -> ()", &attn_enable_wide);
+  m.def("attn_wide4_min_rows(int rows) -> ()", &attn_wide4_min_rows);
   m.def("gemm_force_splitk(int sk) -> ()", &gemm_force_splitk);
   m.def("gemv_force_ks(int ks) -> ()", &gemv_force_ks);
   m.def("decode_gemv_partial(Tensor w, Tensor xin, Tensor(a!) out_f32) -> ()", &decode_gemv_partial);

@@ -257,10 +257,10 @@ __device__ __forceinline__ void attn_buffer_to_lds16(const unsigned char* src, i
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (void __attribute__((address_space(3)))*)lds, 16, voff, 0, 0, 0);
 }
 
-constexpr int AW_WAVES = 8;    // 256 query rows per block
 constexpr int AW_STAGES = 4;   // K / V tiles in the LDS ring: three in flight while one is computed
 
-template <int D, bool CAUSAL>
+// AW_WAVES = 8: 256 query rows per block (long prompts); 4: 128 rows (a few hundred tokens, the ViT)
+template <int D, bool CAUSAL, int AW_WAVES>
 __global__ __launch_bounds__(AW_WAVES * 64) void attn_prefill_wide_kernel(AttnParams p) {
   constexpr int CPR = D / 8;
   constexpr int TILE_BYTES = TK * D * 2;
@@ -441,7 +441,9 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_prefill_wide_kernel(AttnPa
   };
   auto mine = [&](int t) { return wave_active && (!CAUSAL || t * TK <= q_hi + q_off); };
   auto wait_tile = [&]() {   // all but the youngest tile's loads of this wave have landed
-    if constexpr (2 * NIW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    static_assert(2 * NIW == 2 || 2 * NIW == 4 || 2 * NIW == 8, "vmcnt literal");
+    if constexpr (2 * NIW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (2 * NIW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   };
 
@@ -526,7 +528,9 @@ __global__ __launch_bounds__(D) void attn_split_combine_kernel(AttnParams p) {
 }
 
 static int g_attn_wide = 1;   // 0 = never, 1 = by shape, 2 = whenever the strides allow (tests, tuning)
+static int g_attn_wide4_min_rows = 1400;  // fewest query rows that take the 128-row blocks (mode 1): measured crossover 1300-1500 (1024 rows 18.3 vs 18.0 ms per 7B prefill, 1500 rows 25.9 vs 26.2; 636 rows 12.6 vs 12.3, ViT frame 2.50 vs 2.24)
 void attn_enable_wide(int mode) { g_attn_wide = mode; }
+void attn_wide4_min_rows(int rows) { g_attn_wide4_min_rows = rows; }
 
 void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o,
                          const long long* strides /*12: q,k,v,o x (b,s,h)*/, const int* kv_len,
@@ -556,14 +560,19 @@ void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16
     return;
   }
   dim3 block(256);
-  // 128-row blocks once there are enough of them to fill the chip (or the sequence is long enough
-  // that their higher arithmetic intensity wins anyway); K / V must allow 16-byte row chunks
-  constexpr int WIDE_ROWS = AW_WAVES * 32;
-  const long long wide_blocks = static_cast<long long>((Sq + WIDE_ROWS - 1) / WIDE_ROWS) * Hq * B;
+  // Wide blocks (two query tiles per wave, K / V ring in LDS): 256 rows once those fill the chip,
+  // 128 rows for anything from two such blocks up; K / V must allow 16-byte row chunks
   const bool strides_ok = strides[4] % 8 == 0 && strides[7] % 8 == 0 && strides[4] * 2ll * Sk < (1ll << 31) &&
                           strides[7] * 2ll * Sk < (1ll << 31);
-  if (strides_ok && (g_attn_wide == 2 || (g_attn_wide == 1 && Sq >= 512 && wide_blocks >= 256))) {
-    dim3 wgrid(Hq, (Sq + WIDE_ROWS - 1) / WIDE_ROWS, B), wblock(AW_WAVES * 64);
+  const long long blocks256 = static_cast<long long>((Sq + 255) / 256) * Hq * B;
+  int wide = 0;
+  if (strides_ok && g_attn_wide >= 1) {
+    if (Sq >= 512 && blocks256 >= 256) wide = 8;
+    else if (Sq >= g_attn_wide4_min_rows || g_attn_wide == 2) wide = 4;
+  }
+  if (wide) {
+    const int rows = wide * 32;
+    dim3 wgrid(Hq, (Sq + rows - 1) / rows, B), wblock(wide * 64);
     auto go = [&](auto kern, int d) {
       const int smem = AW_STAGES * 2 * TK * d * 2;
       static bool attr_set = false;     // one flag per kernel: the lambda is instantiated per kernel type
@@ -573,12 +582,12 @@ void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16
       }
       hipLaunchKernelGGL(kern, wgrid, wblock, smem, st, p);
     };
-    if (D == 128) {
-      if (causal) go(attn_prefill_wide_kernel<128, true>, 128);
-      else go(attn_prefill_wide_kernel<128, false>, 128);
+    if (wide == 8) {
+      if (D == 128) { if (causal) go(attn_prefill_wide_kernel<128, true, 8>, 128); else go(attn_prefill_wide_kernel<128, false, 8>, 128); }
+      else { if (causal) go(attn_prefill_wide_kernel<64, true, 8>, 64); else go(attn_prefill_wide_kernel<64, false, 8>, 64); }
     } else {
-      if (causal) go(attn_prefill_wide_kernel<64, true>, 64);
-      else go(attn_prefill_wide_kernel<64, false>, 64);
+      if (D == 128) { if (causal) go(attn_prefill_wide_kernel<128, true, 4>, 128); else go(attn_prefill_wide_kernel<128, false, 4>, 128); }
+      else { if (causal) go(attn_prefill_wide_kernel<64, true, 4>, 64); else go(attn_prefill_wide_kernel<64, false, 4>, 64); }
     }
     return;
   }

@@ -26,7 +26,8 @@ def wide():
 @pytest.mark.parametrize("D,H,Hkv,Sq,Sk,causal", [
     (128, 4, 4, 641, 641, True), (128, 8, 2, 300, 300, True), (128, 2, 2, 129, 700, True), (128, 2, 2, 128, 128, True),
     (64, 16, 16, 577, 577, False), (64, 4, 4, 250, 250, False), (128, 2, 2, 1, 130, True), (64, 2, 2, 130, 259, True),
-    (128, 4, 4, 1500, 1500, True), (128, 2, 1, 257, 1000, False), (128, 2, 2, 700, 2300, True)])
+    (128, 4, 4, 1500, 1500, True), (128, 2, 1, 257, 1000, False), (128, 2, 2, 700, 2300, True),
+    (128, 16, 4, 2100, 2100, True), (64, 32, 32, 1100, 1100, False)])    # enough 256-row blocks for the 8-wave variant
 def test_wide_attention_matches_reference(dev, wide, D, H, Hkv, Sq, Sk, causal):
     B = 2
     q, k, v = _rand(B, Sq, H, D, dev=dev), _rand(B, Sk, Hkv, D, dev=dev, seed=1), _rand(B, Sk, Hkv, D, dev=dev, seed=2)
