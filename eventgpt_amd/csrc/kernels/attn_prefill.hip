@@ -260,15 +260,15 @@ __device__ __forceinline__ void attn_buffer_to_lds16(const unsigned char* src, i
 constexpr int AW_STAGES = 4;   // K / V tiles in the LDS ring: three in flight while one is computed
 
 // AW_WAVES = 8: 256 query rows per block (long prompts); 4: 128 rows (a few hundred tokens, the ViT)
-template <int D, bool CAUSAL, int AW_WAVES>
+// QT: 16-row query tiles per wave (2: every K / V fragment feeds two MFMAs; 1: twice the blocks)
+template <int D, bool CAUSAL, int AW_WAVES, int QT = 2>
 __global__ __launch_bounds__(AW_WAVES * 64) void attn_prefill_wide_kernel(AttnParams p) {
   constexpr int CPR = D / 8;
   constexpr int TILE_BYTES = TK * D * 2;
   constexpr int NIW = TILE_BYTES / 1024 / AW_WAVES;   // 1 KB staging instructions per wave and tile
   constexpr int KS = D / 32;
   constexpr int DT = D / 16;
-  constexpr int QT = 2;
-  constexpr int BR = AW_WAVES * 32;                   // query rows per block
+  constexpr int BR = AW_WAVES * 16 * QT;              // query rows per block
   static_assert(NIW >= 1, "a tile is at least one staging instruction per wave");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [stage][K | V]
 
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_prefill_wide_kernel(AttnPa
   const int q_off = p.q_offset_from_len ? (Sk - p.Sq) : p.q_offset;
   // causal: the blocks with the most keys start first
   const int qb0 = (CAUSAL ? gridDim.y - 1 - blockIdx.y : blockIdx.y) * BR;
-  const int qw0 = qb0 + wid * 32;            // first query row of this wave
+  const int qw0 = qb0 + wid * 16 * QT;       // first query row of this wave
 
   bf16x8_t qf[QT][KS];
   int qi[QT];
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_prefill_wide_kernel(AttnPa
   if (CAUSAL) k_end = min(Sk, min(qb0 + BR - 1, p.Sq - 1) + q_off + 1);
   const int ntiles = (k_end + TK - 1) / TK;
   const bool wave_active = qw0 < p.Sq;
-  const int q_hi = min(qw0 + 31, p.Sq - 1);   // last query row of this wave
+  const int q_hi = min(qw0 + 16 * QT - 1, p.Sq - 1);   // last query row of this wave
 
   f32x4_t o[QT][DT];
   float m[QT], l[QT];
@@ -565,13 +565,14 @@ void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16
   const bool strides_ok = strides[4] % 8 == 0 && strides[7] % 8 == 0 && strides[4] * 2ll * Sk < (1ll << 31) &&
                           strides[7] * 2ll * Sk < (1ll << 31);
   const long long blocks256 = static_cast<long long>((Sq + 255) / 256) * Hq * B;
-  int wide = 0;
+  int wide = 0;             // waves per block of the ring-staged kernel (0: not used)
+  constexpr int qt = 2;     // query tiles per wave
   if (strides_ok && g_attn_wide >= 1) {
     if (Sq >= 512 && blocks256 >= 256) wide = 8;
     else if (Sq >= g_attn_wide4_min_rows || g_attn_wide == 2) wide = 4;
   }
   if (wide) {
-    const int rows = wide * 32;
+    const int rows = wide * 16 * qt;
     dim3 wgrid(Hq, (Sq + rows - 1) / rows, B), wblock(wide * 64);
     auto go = [&](auto kern, int d) {
       const int smem = AW_STAGES * 2 * TK * d * 2;

@@ -85,3 +85,4 @@ def test_wide_forward_feeds_backward(dev, wide):
     ref.attention(qf, kf, vf, True).backward(go.float())
     for got, want in ((q.grad, qf.grad), (k.grad, kf.grad), (v.grad, vf.grad)):
         assert torch.allclose(got.float(), want, atol=3e-2, rtol=3e-2), float((got.float() - want).abs().max())
+
