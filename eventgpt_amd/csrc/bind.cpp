@@ -123,6 +123,22 @@ Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bia
   return y;
 }
 
+// h [.., I] = silu(x · Wgate^T) * (x · Wup^T), w_gate_up = [gate rows | up rows] ([2I, K]); more than 32 rows
+// (fewer take the weight-streaming / split-K paths, whose consumers apply the activation)
+Tensor linear_swiglu(const Tensor& x, const Tensor& w) {
+  check_bf16(x, "x"); check_bf16(w, "w_gate_up");
+  const int64_t K = x.size(-1), I = w.size(0) / 2, M = K ? x.numel() / K : 0;
+  TORCH_CHECK(w.dim() == 2 && w.size(1) == K && w.size(0) % 2 == 0, "linear_swiglu: w_gate_up is [2I, K]");
+  TORCH_CHECK(K % 64 == 0 && I % 32 == 0, "linear_swiglu: K % 64 == 0 and I % 32 == 0");
+  TORCH_CHECK(2 * I * K * 2 < (1ll << 31) && M * K * 2 < (1ll << 31), "linear_swiglu: operands over 2 GiB");
+  auto out_sizes = x.sizes().vec();
+  out_sizes.back() = I;
+  Tensor h = at::empty(out_sizes, x.options());
+  if (M > 0)
+    evgpt::launch_gemm_glu(bptr(x), bptr(w), bptr_mut(h), (int)M, (int)I, (int)K, (int)K, (int)K, (int)I, cur_stream());
+  return h;
+}
+
 // C [M,N] = opA(a) · opW(w)^T on the MFMA GEMM with either operand K-strided:
 //   a_t = false: a is [M,K]      a_t = true: a is [Kr,M] (the contraction runs over a's rows)
 //   w_t = false: w is [N,K]      w_t = true: w is [Kr,N]
@@ -998,6 +1014,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("add_rmsnorm(Tensor x, Tensor res, Tensor w, float eps) -> (Tensor, Tensor)", &add_rmsnorm);
   m.def("layernorm(Tensor x, Tensor w, Tensor? b, float eps, int act=0) -> Tensor", &layernorm);
   m.def("linear(Tensor x, Tensor w, Tensor? bias, Tensor? res, int act, bool out_f32) -> Tensor", &linear);
+  m.def("linear_swiglu(Tensor x, Tensor w_gate_up) -> Tensor", &linear_swiglu);
   m.def("linear_partial(Tensor x, Tensor w) -> Tensor", &linear_partial);
   m.def("linear_t(Tensor a, Tensor w, bool a_t, bool w_t, Tensor? bias, Tensor? res, int act, bool out_f32, int K) -> Tensor", &linear_t);
   m.def("gemv_max_batch() -> int", []() -> int64_t { return evgpt::gemv_max_batch(); });

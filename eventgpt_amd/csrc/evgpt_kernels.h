@@ -65,6 +65,8 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
                       const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
                       float* amax_val, int* amax_idx, float* splitk_ws, int splitk,
                       hipStream_t st);
+void launch_gemm_glu(const bf16_t* A, const bf16_t* W, bf16_t* H, int M, int I, int K, int lda, int ldw, int ldc,
+                     hipStream_t st);
 int gemm_splitk_t(int M, int N, int K);   // K splits for launch_gemm_bf16_t (1 = none)
 void launch_gemm_bf16_t(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,
                         const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,

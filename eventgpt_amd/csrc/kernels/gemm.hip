@@ -69,6 +69,12 @@ struct GemmParams {
   // K-strided operands only: k-rows that exist in memory.  A padded contraction (K rounded up
   // to 64) re-reads the last real row for k >= k_rows; the other operand holds zeros there.
   int ka_rows, kw_rows;
+  // Gated-linear-unit mode (K-contiguous operands, no K split): W is [gate rows | up rows], each
+  // glu_half rows; the output has glu_half (= N) columns  silu(x·gate_n) * (x·up_n).  A block stages,
+  // for every wave column, half of its tile rows from the gate region and the matching half from the
+  // up region, so a lane holds both factors of its output columns and the intermediate [M, 2I]
+  // tensor is never written.
+  int glu_half;
 };
 
 // wait until at most `n` of this wave's direct-to-LDS loads are still in flight
@@ -121,6 +127,35 @@ template <int TM, int TN, int WM, int WN, int WGN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc)[TM][TN], int m0, int n0, int wr,
                                               int wc, int tn, int tiles_n, int ksplit, int lane) {
   const int frow = lane & 15, fq = lane >> 4;
+  if constexpr (TN % 2 == 0) {
+    if (p.glu_half) {
+      // tile columns j < TN/2 are gate, j + TN/2 the matching up columns; both factors are rounded to
+      // bf16 first (what a separate activation kernel would read back)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wr * WM + i * 16 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN / 2; ++j) {
+          const int n = n0 + wc * (WN / 2) + j * 16 + fq * 4;
+          if (n >= p.N) continue;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            v[r] = silu_f(bf16_to_f32(f32_to_bf16(acc[i][j][r]))) * bf16_to_f32(f32_to_bf16(acc[i][j + TN / 2][r]));
+          const size_t o = static_cast<size_t>(m) * p.ldc + n;
+          if (n + 3 < p.N && (p.ldc & 3) == 0) {
+            u32x2_t w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2_t*>(p.C + o) = w;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) p.C[o + r] = f32_to_bf16(v[r]);
+          }
+        }
+      }
+      return;
+    }
+  }
   if (p.splitk > 1 || p.raw_partial) {
     float* slab = p.partial + static_cast<size_t>(ksplit) * p.M * p.N;
 #pragma unroll
@@ -229,14 +264,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int bn_out = p.glu_half ? BN / 2 : BN;      // output columns per tile
+  const int tiles_n = (p.N + bn_out - 1) / bn_out, tiles_m = (p.M + BM - 1) / BM;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n * p.splitk);
   const int tile = bid / p.splitk, ksplit = bid % p.splitk;
   const int k_begin = ksplit * p.k_per_split;
   const int k_len = min(p.k_per_split, p.K - k_begin);
   // consecutive tiles walk down M first: they share one weight panel
   const int tm = tile % tiles_m, tn = tile / tiles_m;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BM, n0 = tn * bn_out;
   const int wr = wid / WGN, wc = wid % WGN;
 
   // ---- staging: one wave-instruction = 1 KiB of the LDS image (8 rows x 128 B of a
@@ -275,12 +311,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     } else {
       const int row = rg * 8 + srow;
       const int c = schunk ^ ((row >> 1) & 7);
-      voff_w[i] = ((n0 + row) * p.ldw + c * 8) * 2;
+      int src = n0 + row;
+      if (p.glu_half) {    // wave column's tile rows: first half gate, second half the matching up rows
+        const int wcol = row / WN, within = row % WN;
+        src = (within >= WN / 2 ? p.glu_half - WN / 2 : 0) + n0 + wcol * (WN / 2) + within;
+      }
+      voff_w[i] = (src * p.ldw + c * 8) * 2;
     }
   }
   // bytes of each operand that exist in memory (everything past them reads as zero)
   const long long bytes_a = 2ll * (AT ? p.ka_rows : p.M) * p.lda;
-  const long long bytes_w = 2ll * (BT ? p.kw_rows : p.N) * p.ldw;
+  const long long bytes_w = 2ll * (BT ? p.kw_rows : (p.glu_half ? 2 * p.glu_half : p.N)) * p.ldw;
   auto stage = [&](int buf, int kt) {
     unsigned char* base = smem + buf * STAGE;
     const int k0 = k_begin + kt * BK;
@@ -401,13 +442,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
-  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int bn_out = p.glu_half ? BN / 2 : BN;      // gated mode: W-sub0 holds gate rows, W-sub1 the up rows
+  const int tiles_n = (p.N + bn_out - 1) / bn_out, tiles_m = (p.M + BM - 1) / BM;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n * p.splitk);
   const int tile = bid / p.splitk, ksplit = bid % p.splitk;
   const int k_begin = ksplit * p.k_per_split;
   const int k_len = min(p.k_per_split, p.K - k_begin);
   const int tm = tile % tiles_m, tn = tile / tiles_m;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BM, n0 = tn * bn_out;
   const int nk = k_len / BK;
 
   // ---- staging: image = 16 wave-instructions of 1 KB, two per wave.  Per-lane source offsets
@@ -432,11 +474,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     } else {
       const int lr = rg * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((lr >> 1) & 7);
-      voff_w[i] = ((n0 + (lr >> 5) * 64 + (lr & 31)) * p.ldw + c * 8) * 2;
+      voff_w[i] = ((n0 + (lr >> 5) * (p.glu_half ? 32 : 64) + (lr & 31)) * p.ldw + c * 8) * 2;
     }
   }
   const long long bytes_a = 2ll * (AT ? p.ka_rows : p.M) * p.lda;
-  const long long bytes_w = 2ll * (BT ? p.kw_rows : p.N) * p.ldw;
+  const long long bytes_w = 2ll * (BT ? p.kw_rows : (p.glu_half ? 2 * p.glu_half : p.N)) * p.ldw;
   // which: 0 = A-sub0, 1 = A-sub1, 2 = W-sub0, 3 = W-sub1; kt may run past nk (zero fill)
   auto stage = [&](int which, int kt) {
     const int k0 = k_begin + kt * BK, h = which & 1;
@@ -449,7 +491,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
       buffer_to_lds16(src, lim, dst, voff_a[0]);
       buffer_to_lds16(src, lim, dst + 1024, voff_a[1]);
     } else {
-      const long long adv = BT ? 2ll * k0 * p.ldw + 2ll * h * 32 : 2ll * k0 + 2ll * h * 32 * p.ldw;
+      const long long adv = BT ? 2ll * k0 * p.ldw + 2ll * h * 32
+                               : 2ll * k0 + 2ll * h * (p.glu_half ? p.glu_half : 32) * p.ldw;
       const long long left = bytes_w - adv;
       const unsigned char* src = reinterpret_cast<const unsigned char*>(p.W) + adv;
       const int lim = static_cast<int>(left > 0 ? left : 0);
@@ -562,7 +605,8 @@ void gemm_enable_256(bool on) { g_use_256 = on; }
 
 template <bool AT, bool BT>
 static void launch_256(const GemmParams& p, hipStream_t st) {
-  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256) * p.splitk;
+  const int bn_out = p.glu_half ? 128 : 256;
+  const int tiles = ((p.M + 255) / 256) * ((p.N + bn_out - 1) / bn_out) * p.splitk;
   constexpr int smem = 128 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
@@ -606,7 +650,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 
 template <int BM, int BN, int WGM, int WGN, int STAGES, bool AT = false, bool BT = false>
 static void launch_cfg(const GemmParams& p, hipStream_t st) {
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk;
+  const int bn_out = p.glu_half ? BN / 2 : BN;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + bn_out - 1) / bn_out) * p.splitk;
   constexpr size_t smem = static_cast<size_t>(STAGES) * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
@@ -770,6 +815,20 @@ int gemm_splitk_t(int M, int N, int K) {
   if (M > 1024 || K < 8192 || t < 96 || t >= 256 || g_forced_cfg >= 0) return 1;
   const int s = static_cast<int>(512 / t);
   return s < 1 ? 1 : (s > 4 ? 4 : s);
+}
+
+// H[M, I] = silu(A · Wgate^T) * (A · Wup^T) with W = [gate rows | up rows] ([2I, K]): the gate/up
+// projection of a SwiGLU MLP with the activation applied in the epilogue (GemmParams::glu_half).
+void launch_gemm_glu(const bf16_t* A, const bf16_t* W, bf16_t* H, int M, int I, int K, int lda, int ldw, int ldc,
+                     hipStream_t st) {
+  GemmParams p{A, W, H, nullptr, nullptr, nullptr, M, I, K, lda, ldw, ldc, ACT_NONE, nullptr, nullptr, 1, K,
+               nullptr, 0, K, K};
+  p.glu_half = I;
+  auto tiles = [&](int bm, int bn) { return static_cast<long long>((M + bm - 1) / bm) * ((2 * I + bn - 1) / bn); };
+  if (g_forced_cfg == CFG_256x256 || (g_forced_cfg < 0 && use_256(M, 2 * I))) launch_256<false, false>(p, st);
+  else if (g_forced_cfg == CFG_128x128 || (g_forced_cfg < 0 && tiles(128, 128) >= 384)) launch_cfg<128, 128, 2, 2, 2>(p, st);
+  else if (g_forced_cfg == CFG_64x64) launch_cfg<64, 64, 2, 2, 4>(p, st);
+  else launch_cfg<64, 128, 2, 2, 3>(p, st);
 }
 
 // C[M,N] = opA · opW^T with K-strided operands: a_t -> A is stored [K][M] (lda = its row

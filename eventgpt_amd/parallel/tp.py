@@ -351,8 +351,8 @@ class TensorParallelEngine(GenerationEngine):
             raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
             x = self._reduce(raw.linear(o.view(1, S, self.Hq * self.D), l.w_o, None,
                                         x if lead else None, 0, False))
-            gu = raw.linear(raw.rmsnorm(x, l.norm2, self.eps), l.w_gate_up, None, None, 0, False)
-            x = self._reduce(raw.linear(raw.swiglu(gu), l.w_down, None, x if lead else None, 0, False))
+            h = self._mlp_up(raw.rmsnorm(x, l.norm2, self.eps), l.w_gate_up)
+            x = self._reduce(raw.linear(h, l.w_down, None, x if lead else None, 0, False))
         return x
 
     def _layers_step(self) -> None:
@@ -387,8 +387,8 @@ class TensorParallelEngine(GenerationEngine):
             raw.decode_attn(self.q, l.k_cache, l.v_cache, self.attn, self.part_o, self.part_ml,
                             self.pos, self.nsplit, self.scale)
             x = self._reduce(raw.linear(self.attn, l.w_o, None, x if lead else None, 0, False))
-            gu = raw.linear(raw.rmsnorm(x, l.norm2, self.eps), l.w_gate_up, None, None, 0, False)
-            x = self._reduce(raw.linear(raw.swiglu(gu), l.w_down, None, x if lead else None, 0, False))
+            h = self._mlp_up(raw.rmsnorm(x, l.norm2, self.eps), l.w_gate_up)
+            x = self._reduce(raw.linear(h, l.w_down, None, x if lead else None, 0, False))
         self.x.copy_(x)
 
     # ------------------------------------------------------------------ head

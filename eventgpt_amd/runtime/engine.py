@@ -333,6 +333,14 @@ class GenerationEngine:
     # RMSNorm, SwiGLU) is done by the kernel that sums the slabs.
     fused_rows = 32
 
+    def _mlp_up(self, xn: torch.Tensor, w_gate_up: torch.Tensor) -> torch.Tensor:
+        """``silu(xn Wgate^T) * (xn Wup^T)``: above 32 rows the GEMM applies the activation in its
+        epilogue (the ``[rows, 2I]`` intermediate is never written); below, GEMM + activation kernel."""
+        rows = xn.numel() // xn.shape[-1]
+        if rows > 32 and (w_gate_up.shape[0] // 2) % 32 == 0 and xn.shape[-1] % 64 == 0:
+            return self.raw.linear_swiglu(xn, w_gate_up)
+        return self.raw.swiglu(self.raw.linear(xn, w_gate_up, None, None, 0, False))
+
     def _few_rows_ok(self, rows: int) -> bool:
         return (3 < rows <= self.fused_rows and self.H % 64 == 0
                 and self.I % 64 == 0 and (self.Hq * self.D) % 64 == 0)
@@ -387,8 +395,7 @@ class GenerationEngine:
             raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
             x = raw.linear(o.view(1, S, self.Hq * self.D), self._w(l, "w_o"), None, x, 0, False)
             xn = raw.rmsnorm(x, l.norm2, self.eps)
-            gu = raw.linear(xn, self._w(l, "w_gate_up"), None, None, 0, False)
-            x = raw.linear(raw.swiglu(gu), self._w(l, "w_down"), None, x, 0, False)
+            x = raw.linear(self._mlp_up(xn, self._w(l, "w_gate_up")), self._w(l, "w_down"), None, x, 0, False)
         return x
 
     # ----------------------------------------------------- speculative verify

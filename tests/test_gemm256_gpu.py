@@ -114,3 +114,24 @@ def test_auto_dispatch_column_split_for_partial_rounds(dev, M, N, K):
     r2 = res.clone()
     y2 = hip.raw.linear(x, w, None, r2, 0, False)          # plain residual
     _check(y2, (x.float() @ w.float().t()).to(torch.bfloat16).float() + res.float(), K)
+
+
+@pytest.mark.parametrize("M,I,K,cfg", [(636, 11008, 4096, -1), (4643, 1408, 512, -1), (100, 96, 64, -1), (300, 2816, 1024, 0),
+                                       (300, 2816, 1024, 1), (300, 2816, 1024, 2), (1030, 704, 256, 5), (257, 32, 128, 5)])
+def test_linear_swiglu_epilogue(dev, M, I, K, cfg):
+    """Gate/up projection with the activation in the GEMM epilogue == GEMM, then the activation kernel
+    (bitwise: both round the two factors to bf16 before multiplying), on every tile config."""
+    from eventgpt_amd.ops import hip
+    x, w = _rand(M, K, dev=dev), _rand(2 * I, K, dev=dev, seed=1, scale=0.05)
+    hip.raw.gemm_force_config(cfg)
+    try:
+        fused = hip.raw.linear_swiglu(x, w)
+        again = hip.raw.linear_swiglu(x, w)
+    finally:
+        hip.raw.gemm_force_config(-1)
+    plain = hip.raw.swiglu(hip.raw.linear(x, w, None, None, 0, False))
+    assert fused.shape == (M, I) and torch.equal(fused, again)
+    gu = x.float() @ w.float().t()
+    want = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
+    _check(fused, want, K)
+    assert torch.allclose(fused.float(), plain.float(), atol=2e-2 * float(want.abs().max()), rtol=2e-2)
