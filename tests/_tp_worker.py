@@ -14,8 +14,9 @@ from eventgpt_amd.parallel.tp import TensorParallelDecoder, gather_vocab_shards,
 
 def main(out_path):
     info = init_distributed(use_gpu=False)
+    heads = max(4, info.world)            # every rank owns at least one head
     cfg = EventChatConfig(vocab_size=203, hidden_size=64, intermediate_size=172,
-                          num_hidden_layers=2, num_attention_heads=4, max_position_embeddings=128,
+                          num_hidden_layers=2, num_attention_heads=heads, max_position_embeddings=128,
                           torch_dtype="float32")
     model = EventChatModel.from_config(cfg, torch.float32, "cpu", seed=5)
     g = torch.Generator().manual_seed(3)

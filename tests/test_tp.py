@@ -1,4 +1,4 @@
-"""Tensor parallelism: sharded decoder (2 and 4 gloo ranks) == unsharded model."""
+"""Tensor parallelism: sharded decoder (2, 4 and 8 gloo ranks) == unsharded model."""
 import json
 import os
 import subprocess
@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 @pytest.mark.timeout(240)
-@pytest.mark.parametrize("world,port", [(2, 29541), (4, 29542)])
+@pytest.mark.parametrize("world,port", [(2, 29541), (4, 29542), (8, 29543)])
 def test_tp_decoder_matches_full_model(tmp_path, world, port):
     out = str(tmp_path / "tp.json")
     env = dict(os.environ, OMP_NUM_THREADS="1")
