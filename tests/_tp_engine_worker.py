@@ -1,11 +1,12 @@
-"""Worker for the GPU tensor-parallel engine test: two ranks share GPU 0, the process
+"""Worker for the GPU tensor-parallel engine tests: the ranks (two or eight) share GPU 0, the process
 group is gloo (host tensors only), graphs are off (a host copy cannot be captured).
 
-Runs the sharded engine in four configurations -- 2 and 6 streams (the weight-streaming
+Two ranks run the sharded engine in four configurations -- 2 and 6 streams (the weight-streaming
 GEMV path and the split-K GEMM + fused-consumer path), each with the library all-reduce
 (gloo through host copies) and with the one-shot push all-reduce over IPC-mapped buffers
 (two processes, one GPU: real ``hipIpcMemHandle`` exchange, every device wait bounded) --
-and compares each against the unsharded engine on the same prompts."""
+and compare each against the unsharded engine on the same prompts; eight ranks (one attention
+head, 192 padded MLP columns and 65 vocabulary rows each) run the library all-reduce only."""
 import json
 import os
 import sys
@@ -75,16 +76,20 @@ def run_config(model_fn, info, prompts, want_x, allreduce):
 def main(out_path):
     info = init_distributed(backend="gloo", use_gpu=True)
     dev = info.device
-    cfg = EventChatConfig(vocab_size=515, hidden_size=512, intermediate_size=1408, num_hidden_layers=2,
-                          num_attention_heads=4, max_position_embeddings=512)
+    # head_dim stays 128; with more than four ranks the model gets one head per rank
+    heads = max(4, info.world)
+    cfg = EventChatConfig(vocab_size=515, hidden_size=128 * heads, intermediate_size=1408, num_hidden_layers=2,
+                          num_attention_heads=heads, max_position_embeddings=512)
+    H = cfg.hidden_size
+    modes = ("rccl", "oneshot") if info.world == 2 else ("rccl",)   # the IPC all-reduce is exercised by two processes
     model_fn = lambda: EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=3)   # noqa: E731
     out = {}
     for B in (2, 6):
-        prompts = [(torch.randn(20 + 3 * b, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(b))
+        prompts = [(torch.randn(20 + 3 * b, H, device=dev, generator=torch.Generator(device=dev).manual_seed(b))
                     * 0.5).to(torch.bfloat16) for b in range(B)]
         want, want_x = reference(model_fn(), prompts)
         print(f"rank {info.rank}: single-engine reference for {B} streams done", flush=True)
-        for ar in ("rccl", "oneshot"):
+        for ar in modes:
             print(f"rank {info.rank}: {B} streams, allreduce={ar}", flush=True)
             res = run_config(model_fn, info, prompts, want_x, ar)
             res["want"] = want

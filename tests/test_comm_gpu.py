@@ -1,6 +1,8 @@
 """One-shot all-reduce (csrc/kernels/comm.hip) on ONE GPU: W virtual ranks driven by a single
 launch (every block co-resident), checked against a plain fp32 sum; graph replays; the
 bounded wait's give-up path forced from the host; the vocab-parallel argmax pair kernels."""
+import os
+
 import pytest
 import torch
 
@@ -168,3 +170,55 @@ def test_argmax_pair_kernels(dev):
     want = torch.where(v == best, i, torch.full_like(i, 1 << 40)).min(1).values
     assert tok.long().tolist() == want.tolist()
     assert int(tok[0]) == 1 * per + 9
+
+
+_RCCL_CAPTURE = r"""
+import os, sys, json
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", sys.argv[1])
+import torch, torch.distributed as dist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+t = torch.ones(4, 4096, device=dev)
+pair = torch.arange(8, device=dev, dtype=torch.int32)
+pairs = torch.zeros(8, device=dev, dtype=torch.int32)
+dist.all_reduce(t)                      # communicator comes up before any capture
+dist.all_gather_into_tensor(pairs, pair)
+torch.cuda.synchronize()
+src = torch.zeros(4, 4096, device=dev)
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g, capture_error_mode="thread_local"):
+    t.copy_(src)
+    t.mul_(2.0)
+    dist.all_reduce(t)
+    dist.all_gather_into_tensor(pairs, pair)
+    out = t + 1.0
+ok = []
+for i in range(4):
+    src.fill_(float(i))
+    pair.fill_(i)
+    g.replay()
+    torch.cuda.synchronize()
+    ok.append(bool((out == 2.0 * i + 1.0).all()) and bool((pairs == i).all()))
+    _ = torch.randn(64, device=dev).sum().item()       # eager work between the replays
+print(json.dumps({"ok": ok, "backend": dist.get_backend()}))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.timeout(240)
+def test_rccl_collectives_record_into_a_graph_single_rank():
+    """The library collectives of the tensor-parallel decode step (fp32 all-reduce, int32
+    all-gather) are recorded into a HIP graph and replayed, on the RCCL backend itself; one rank is
+    all a one-GPU box can form, so this pins the capture path, not the fabric."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    print("launching single-rank RCCL capture worker", flush=True)
+    r = subprocess.run([sys.executable, "-c", _RCCL_CAPTURE, "29561"], env=env, capture_output=True, text=True,
+                       timeout=220)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2500:])
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["backend"] == "nccl" and got["ok"] == [True] * 4, got

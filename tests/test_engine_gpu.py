@@ -220,6 +220,34 @@ def test_tensor_parallel_engine_two_ranks(tmp_path):
             assert got["cos_prefill"][b] > 0.999 and got["cos_step"][b] > 0.995, (key, got)
 
 
+@pytest.mark.timeout(300)
+def test_tensor_parallel_engine_eight_ranks(tmp_path):
+    """The sharding an 8-GPU node uses (one attention head, 176 -> 192 padded MLP columns and 65
+    vocabulary rows per rank, the last rank's rows partly padding) on real kernels: eight processes
+    share GPU 0 and the collectives go through host copies."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "tp_engine8.json")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+           "--master-addr", "127.0.0.1", "--master-port", "29549", os.path.join(here, "_tp_engine_worker.py"), out]
+    print("launching 8-rank TP engine worker", flush=True)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    allgot = json.load(open(out))
+    for key in ("b2_rccl", "b6_rccl"):
+        got = allgot[key]
+        assert got["heads_local"] == 1 and got["i_local"] == 192 and got["logits_width"] == 515, (key, got["i_local"])
+        assert len(got["ranks"]) == 8 and all(rk == got["ranks"][0] for rk in got["ranks"]), key
+        assert got["logits_equal"], key
+        for b, want in enumerate(got["want"]):
+            assert got["first_tok"][b] == want[0] == got["ranks"][0][b][0], (key, b)
+            assert got["cos_prefill"][b] > 0.999 and got["cos_step"][b] > 0.995, (key, got["cos_prefill"], got["cos_step"])
+
+
 def test_continuous_batching_matches_single_stream(model, dev):
     """7 requests of different lengths and budgets through 3 slots: every request gets the
     tokens its own single-stream greedy decode produces, slots are reused, and sequences
