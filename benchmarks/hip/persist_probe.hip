@@ -190,6 +190,13 @@ __global__ __launch_bounds__(NW * 64, 1) void probe_kernel(Probe p) {
   wait_vm<0>();
 }
 
+// nothing but barriers: what one grid-wide rendezvous costs with idle memory pipes
+__global__ __launch_bounds__(NW * 64, 1) void barrier_only_kernel(Probe p, int n) {
+  unsigned int target = 0;
+  int dead = 0;
+  for (int i = 0; i < n; ++i) grid_sync(p, target, dead);
+}
+
 // plain streaming read of the same bytes: the box's ceiling
 __global__ __launch_bounds__(256) void stream_kernel(const u32x4_t* __restrict__ src, size_t n16, float* out) {
   float a = 0.f;
@@ -302,6 +309,27 @@ int main(int argc, char** argv) {
       printf("plain stream grid %5d: %.3f ms for %.2f GB = %.2f TB/s\n", grid, ms / 5, bytes / 1e9, bytes / (ms / 5) / 1e9);
       fflush(stdout);
     }
+  }
+
+  {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int n = 1000;
+    for (int rep = 0; rep < 2; ++rep) {
+      zero_kernel<<<1, 64>>>(p.bar, 1);
+      CK(hipEventRecord(e0));
+      barrier_only_kernel<<<NB, NW * 64>>>(p, n);
+      CK(hipEventRecord(e1));
+      CK(hipDeviceSynchronize());
+    }
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned int e = 0;
+    CK(hipMemcpy(&e, p.err, 4, hipMemcpyDeviceToHost));
+    printf("barrier only: %.2f us per grid barrier (256 blocks, %d barriers) err=%u\n", ms * 1e3 / n, n, e);
+    fflush(stdout);
+    if (e) return 2;
   }
 
   unsigned int err = 0;
