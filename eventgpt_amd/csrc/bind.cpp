@@ -146,8 +146,12 @@ Tensor linear_swiglu(const Tensor& x, const Tensor& w) {
 // dW = dY^T · X is (a = dY, w = X, both transposed).  A K-contiguous operand must have K % 64 == 0
 // (zero-padded by the caller); K-strided operands may have any number of rows Kr <= K as long as
 // the other operand is zero for k >= Kr.
+// `out`: write the product into this tensor (same dtype and element count as the result) instead of a
+// new one; it may be `res` itself, which makes the call an accumulation (each element is read and
+// written by the same lane).
 Tensor linear_t(const Tensor& a, const Tensor& w, bool a_t, bool w_t, const c10::optional<Tensor>& bias,
-                const c10::optional<Tensor>& res, int64_t act, bool out_f32, int64_t K) {
+                const c10::optional<Tensor>& res, int64_t act, bool out_f32, int64_t K,
+                const c10::optional<Tensor>& out) {
   check_bf16(a, "a"); check_bf16(w, "w");
   TORCH_CHECK(a.dim() == 2 && w.dim() == 2 && (a_t || w_t), "linear_t: 2-D operands, at least one K-strided");
   TORCH_CHECK(K % 64 == 0 && K >= 64, "linear_t: padded contraction length must be a multiple of 64");
@@ -168,7 +172,15 @@ Tensor linear_t(const Tensor& a, const Tensor& w, bool a_t, bool w_t, const c10:
               "columns for k past the real length); the other may stop at the real length");
   if (bias.has_value()) { check_bf16(*bias, "bias"); TORCH_CHECK(bias->numel() == N); }
   if (res.has_value()) { check_bf16(*res, "residual"); TORCH_CHECK(res->numel() == M * N); }
-  Tensor y = at::empty({M, N}, a.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
+  Tensor y;
+  if (out.has_value()) {
+    y = *out;
+    TORCH_CHECK(y.is_cuda() && y.is_contiguous() && y.numel() == M * N &&
+                y.scalar_type() == (out_f32 ? at::kFloat : at::kBFloat16), "linear_t: out must be a contiguous [M, N] "
+                "tensor of the result's dtype");
+  } else {
+    y = at::empty({M, N}, a.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
+  }
   if (M == 0 || N == 0) return y;
   const int sk = evgpt::gemm_splitk_t((int)M, (int)N, (int)K);
   Tensor ws;
@@ -1016,7 +1028,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("linear(Tensor x, Tensor w, Tensor? bias, Tensor? res, int act, bool out_f32) -> Tensor", &linear);
   m.def("linear_swiglu(Tensor x, Tensor w_gate_up) -> Tensor", &linear_swiglu);
   m.def("linear_partial(Tensor x, Tensor w) -> Tensor", &linear_partial);
-  m.def("linear_t(Tensor a, Tensor w, bool a_t, bool w_t, Tensor? bias, Tensor? res, int act, bool out_f32, int K) -> Tensor", &linear_t);
+  m.def("linear_t(Tensor a, Tensor w, bool a_t, bool w_t, Tensor? bias, Tensor? res, int act, bool out_f32, int K, Tensor(a!)? out=None) -> Tensor", &linear_t);
   m.def("gemv_max_batch() -> int", []() -> int64_t { return evgpt::gemv_max_batch(); });
   m.def("reduce_residual_norm(Tensor partial, Tensor? res, Tensor? norm_w, float eps, Tensor(a!)? out) -> (Tensor, Tensor)", &reduce_residual_norm);
   m.def("reduce_swiglu(Tensor partial) -> Tensor", &reduce_swiglu);

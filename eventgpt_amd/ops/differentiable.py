@@ -132,8 +132,10 @@ def linear_dgrad(gy: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     return _raw().linear_t(_pad_cols(gy, _round64(n)), weight, False, True, None, None, 0, False, _round64(n))
 
 
-def linear_wgrad(gy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """``dW [N,K] = dY^T [N,M] @ X [M,K]``: both operands are strided in the token dimension."""
+def linear_wgrad(gy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``dW [N,K] = dY^T [N,M] @ X [M,K]``: both operands are strided in the token dimension.
+    ``out``: a contiguous bf16 ``[N,K]`` tensor the product is written into (an optimizer's
+    flat gradient buffer), instead of a new tensor."""
     m = gy.shape[0]
     mp = _round64(m)
     if mp != m:      # zero rows on the smaller operand; the other one's tail rows are re-read and multiplied by 0
@@ -141,7 +143,7 @@ def linear_wgrad(gy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
             gy = _pad_rows(gy, mp)
         else:
             x = _pad_rows(x, mp)
-    return _raw().linear_t(gy, x, True, True, None, None, 0, False, mp)
+    return _raw().linear_t(gy, x, True, True, None, None, 0, False, mp, out)
 
 
 class _Linear(torch.autograd.Function):
@@ -168,7 +170,20 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = linear_dgrad(g2, weight.contiguous()).view(*gy.shape[:-1], weight.shape[1])
         if ctx.needs_input_grad[1]:
-            dw = linear_wgrad(g2, x2)
+            # an optimizer that keeps gradients in a flat buffer publishes the parameter's slot
+            # as ``_grad_sink``: the first gradient of a step is written there by the GEMM itself
+            # and handed to autograd as that view, which it adopts as ``.grad`` without a copy
+            # (later gradients of the same step are accumulated by autograd as usual)
+            # A weight used several times in one graph gets all its gradients summed by autograd
+            # BEFORE ``.grad`` is set, so "the slot is free" is tracked by the optimizer's own flag
+            # (cleared by its ``zero_grad``), never inferred from ``.grad`` alone.
+            sink = getattr(weight, "_grad_sink", None)
+            if (sink is not None and weight.grad is None and not getattr(weight, "_grad_sink_used", True)
+                    and sink.dtype == g2.dtype and sink.shape == weight.shape and sink.is_contiguous()):
+                weight._grad_sink_used = True
+                dw = linear_wgrad(g2, x2, out=sink).view_as(weight)
+            else:
+                dw = linear_wgrad(g2, x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = g2.float().sum(0).to(gy.dtype)
         return dx, dw, db

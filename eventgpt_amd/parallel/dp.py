@@ -39,12 +39,14 @@ class _Bucket:
         p0 = params[0]
         self.flat_param = torch.zeros(self.padded, dtype=p0.dtype, device=p0.device)
         self.flat_grad = torch.zeros(self.padded, dtype=p0.dtype, device=p0.device)
+        self.grad_views = []
         off = 0
         for p in params:
             n = p.numel()
             self.flat_param[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + n].view_as(p)
             p.grad = self.flat_grad[off:off + n].view_as(p)
+            self.grad_views.append(p.grad)
             off += n
         lo = rank * self.shard_len
         self.shard_slice = slice(lo, lo + self.shard_len)
@@ -66,7 +68,7 @@ class ShardedAdamW:
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3,
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
-                 group=None, bucket_bytes: int = 64 << 20, overlap: bool = True):
+                 group=None, bucket_bytes: int = 64 << 20, overlap: bool = True, direct_grads: bool = True):
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.distributed else 1
@@ -98,9 +100,20 @@ class ShardedAdamW:
         self.overlap = overlap and self.on_rccl
         self.comm_stream = torch.cuda.Stream() if self.on_rccl else None
         self._owner: Dict[int, _Bucket] = {}
+        # Direct gradients: a bf16 matrix on the GPU gets its slot of the flat buffer published as
+        # ``_grad_sink``.  The in-tree wgrad GEMM (``ops/differentiable.py``) writes a step's first
+        # gradient straight into the slot and autograd adopts that view as ``.grad``: no zero fill of
+        # the buffer and no read-modify-write accumulation into it (for a 7B decoder those are 13.6 GB
+        # written plus 41 GB moved per step).  Whatever reaches ``.grad`` some other way is settled into
+        # the slot before the buffer is reduced, so correctness never depends on the shortcut.
+        self._sink: Dict[int, torch.Tensor] = {}
         for b in self.buckets:
-            for p in b.params:
+            for p, view in zip(b.params, b.grad_views):
                 self._owner[id(p)] = b
+                if direct_grads and p.is_cuda and p.dtype == torch.bfloat16 and p.dim() == 2:
+                    p._grad_sink = view
+                    p._grad_sink_used = True   # until the first zero_grad hands the slot out
+                    self._sink[id(p)] = view
                 if self.overlap:
                     p.register_post_accumulate_grad_hook(self._on_grad)
         self._arm()
@@ -111,7 +124,20 @@ class ShardedAdamW:
             b.pending = len(b.params)
             b.work = None
 
+    def _settle(self, p: torch.nn.Parameter) -> None:
+        """Make the flat buffer hold ``p``'s gradient and ``p.grad`` be its slot again."""
+        view = self._sink.get(id(p))
+        if view is None:
+            return
+        g = p.grad
+        if g is None:
+            view.zero_()                       # no gradient this step
+        elif g.data_ptr() != view.data_ptr():
+            view.copy_(g)                      # arrived as a tensor of its own
+        p.grad = view
+
     def _on_grad(self, p: torch.nn.Parameter) -> None:
+        self._settle(p)
         b = self._owner[id(p)]
         b.pending -= 1
         if b.pending == 0:
@@ -136,6 +162,11 @@ class ShardedAdamW:
             b.grad_shard.div_(self.world)
 
     def _finish_reduces(self) -> None:
+        if self._sink:
+            for b in self.buckets:
+                if b.work is None:
+                    for p in b.params:
+                        self._settle(p)
         for b in self.buckets:
             if b.work is None:            # not launched from a hook (no overlap, or a parameter without gradient)
                 self._launch_reduce(b)
@@ -148,7 +179,16 @@ class ShardedAdamW:
     # -------------------------------------------------------------------- step
     def zero_grad(self, set_to_none: bool = False) -> None:
         for b in self.buckets:
-            b.flat_grad.zero_()
+            direct = [id(p) in self._sink for p in b.params]
+            if not any(direct):
+                b.flat_grad.zero_()
+                continue
+            for p, view, d in zip(b.params, b.grad_views, direct):
+                if d:
+                    p.grad = None              # the next gradient is written, not added
+                    p._grad_sink_used = False
+                else:
+                    view.zero_()
         self._arm()
 
     def _global_sq_norm(self) -> torch.Tensor:

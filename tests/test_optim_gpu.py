@@ -51,7 +51,10 @@ def test_sharded_adamw_on_gpu_matches_torch(dtype):
         opt.zero_grad()
         grads = [(torch.randn(*s, generator=g) * 2.0).to(dtype) for s in shapes]
         for p, r, gr in zip(params, ref, grads):
-            p.grad.copy_(gr.to(dev))
+            if p.grad is None:          # bf16 matrices: the slot is handed out again with the next gradient
+                p.grad = gr.to(dev)
+            else:
+                p.grad.copy_(gr.to(dev))
             r.grad = gr.float().clone()
         want_norm = float(torch.nn.utils.clip_grad_norm_(ref, 1.0))
         norm = float(opt.step(max_grad_norm=1.0))
@@ -149,3 +152,53 @@ def test_fused_alignment_loss_matches_tensor_expressions(dtype, masked):
         scale = float(p32.grad.abs().max())
         assert torch.allclose(got_grad.float(), p32.grad, atol=(1e-6 if dtype == torch.float32 else 1e-2) * scale + 1e-9,
                               rtol=1e-4 if dtype == torch.float32 else 2e-2)
+
+
+def test_wgrad_written_straight_into_the_flat_gradient_buffer():
+    """bf16 matrices get the first gradient of a step from the wgrad GEMM directly in their slot of the
+    optimizer's flat buffer (no zero fill, no accumulation pass): same parameters, bit for bit, as the
+    zero-and-accumulate path, also with a layer applied twice and a parameter that gets no gradient."""
+    from eventgpt_amd.models.llama import Linear, RMSNorm
+    from eventgpt_amd.parallel.dp import ShardedAdamW
+    dev = torch.device("cuda:0")
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = Linear(256, 512, bias=False)
+            self.b = Linear(512, 256, bias=False)
+            self.c = Linear(512, 256, bias=False)
+            self.unused = Linear(256, 64, bias=False)
+            self.norm = RMSNorm(256)
+
+        def forward(self, x):
+            h = self.b(self.a(self.norm(x)))
+            return self.c(self.a(h))            # `a` is used twice: autograd sums its two gradients
+
+    def build(direct):
+        torch.manual_seed(0)
+        net = Net().to(dev, torch.bfloat16)
+        opt = ShardedAdamW(net.parameters(), lr=1e-2, weight_decay=0.01, bucket_bytes=1 << 18, direct_grads=direct)
+        return net, opt
+
+    g = torch.Generator(device=dev).manual_seed(1)
+    xs = [torch.randn(96, 256, device=dev, generator=g).to(torch.bfloat16) for _ in range(3)]
+    results = []
+    for direct in (True, False):
+        net, opt = build(direct)
+        for x in xs:
+            opt.zero_grad()
+            if direct:
+                assert net.a.weight.grad is None and net.norm.weight.grad is not None
+            net(x).float().pow(2).mean().backward()
+            if direct:
+                # autograd adopted the slot itself as .grad (nothing was copied)
+                assert net.b.weight.grad.data_ptr() == net.b.weight._grad_sink.data_ptr()
+                assert net.c.weight.grad.data_ptr() == net.c.weight._grad_sink.data_ptr()
+                assert net.unused.weight.grad is None
+            opt.step(max_grad_norm=1.0)
+            if direct:
+                assert float(net.unused.weight.grad.abs().max()) == 0.0      # settled as a zero gradient
+        results.append([p.detach().clone() for p in net.parameters()])
+    for pd, pz in zip(*results):
+        assert torch.equal(pd, pz)
