@@ -121,7 +121,8 @@ class SFTTrainer:
     def __init__(self, model, tokenizer, dataset: InstructionDataset, info, tune: str = "projector",
                  num_frames: int = 5, event_image_key: str = "event_image", learning_rate: float = 1e-3,
                  weight_decay: float = 0.0, warmup_ratio: float = 0.03, gradient_accumulation: int = 1,
-                 max_len: int = 2048, output_dir: str = "tasks/sft", lora: Optional[Dict] = None):
+                 max_len: int = 2048, output_dir: str = "tasks/sft", lora: Optional[Dict] = None,
+                 dgrad_copies: bool = True):
         self.model, self.tok, self.ds, self.info = model, tokenizer, dataset, info
         self.tune, self.num_frames, self.key = tune, num_frames, event_image_key
         self.accum, self.max_len, self.out = max(1, gradient_accumulation), max_len, output_dir
@@ -130,6 +131,12 @@ class SFTTrainer:
         if info.world > 1:
             broadcast_parameters(model)
         self.opt = ShardedAdamW(self.params, lr=learning_rate, weight_decay=weight_decay, overlap=False)
+        # frozen decoder weights (projector / LoRA tuning): keep K-contiguous copies for the
+        # input-gradient GEMMs when the device has the room (one more copy of the frozen matrices)
+        self.dgrad_copy_bytes = 0
+        if dgrad_copies and tune != "full" and next(model.parameters()).is_cuda:
+            from ..ops.differentiable import enable_transposed_dgrad
+            self.dgrad_copy_bytes = enable_transposed_dgrad(model.get_model().layers)
         self.history: List[Dict] = []
         self.step = 0
         os.makedirs(output_dir, exist_ok=True)

@@ -320,8 +320,14 @@ class EventChatModel(nn.Module):
     # ------------------------------------------------------------------ vision
     def visval_encode(self, event_tensor: torch.Tensor) -> torch.Tensor:
         """``[B,3,H,W]`` → projector output ``[B, 577, hidden]`` (tower is frozen)."""
-        with torch.no_grad():
-            feats = self.get_model().visual_tower.visual_tower(event_tensor).last_hidden_state
+        if (torch.is_grad_enabled() and event_tensor.is_cuda and self.dtype == torch.bfloat16
+                and getattr(self, "train_tower_on_engine", True)):
+            # a training step: the frozen tower is one graph replay of the serving engine's launch
+            # sequence instead of ~300 eager launches; projector and adaptor stay on autograd
+            feats = self.vision_engine().encode_tower(event_tensor)
+        else:
+            with torch.no_grad():
+                feats = self.get_model().visual_tower.visual_tower(event_tensor).last_hidden_state
         feats = feats.detach()
         if torch.is_grad_enabled():
             feats.requires_grad_(True)

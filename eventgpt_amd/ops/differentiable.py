@@ -146,6 +146,41 @@ def linear_wgrad(gy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] 
     return _raw().linear_t(gy, x, True, True, None, None, 0, False, mp, out)
 
 
+def enable_transposed_dgrad(module: torch.nn.Module, min_free_bytes: int = 32 << 30) -> int:
+    """Give every FROZEN bf16 weight matrix of ``module`` a row-major copy of its transpose for the
+    input-gradient product.  ``dX = dY W`` contracts over W's rows; read from ``W`` itself that is the
+    K-strided operand path (transposing LDS reads, 420-660 TFLOP/s at ~840 tokens), read from
+    ``W^T [K, N]`` it is the plain product the forward runs (750-880).  Only weights that do not
+    train qualify (the copy would be stale after every optimizer step), and only while at least
+    ``min_free_bytes`` of device memory stay free.  Returns the bytes spent.  A copy is refreshed
+    if its weight was written in place or moved since (``_version`` / ``data_ptr``)."""
+    spent = 0
+    for m in module.modules():
+        w = getattr(m, "weight", None)
+        if not isinstance(m, torch.nn.Linear) or w is None or w.requires_grad or not _fused(w):
+            continue
+        n, k = w.shape
+        if n % 64 or k % 8 or getattr(w, "_dgrad_t", None) is not None:
+            continue
+        need = w.numel() * w.element_size()
+        if torch.cuda.mem_get_info(w.device)[0] - need < min_free_bytes:
+            break
+        w._dgrad_t = (w.detach().t().contiguous(), w._version, w.data_ptr())
+        spent += need
+    return spent
+
+
+def _transposed_for_dgrad(weight) -> Optional[torch.Tensor]:
+    ent = getattr(weight, "_dgrad_t", None)
+    if ent is None or weight.requires_grad:
+        return None
+    wt, version, ptr = ent
+    if version != weight._version or ptr != weight.data_ptr():
+        wt.copy_(weight.detach().t())
+        weight._dgrad_t = (wt, weight._version, weight.data_ptr())
+    return wt
+
+
 class _Linear(torch.autograd.Function):
     """``y = x @ W^T + b`` on the in-tree MFMA GEMM, forward and both backward products."""
 
@@ -168,7 +203,12 @@ class _Linear(torch.autograd.Function):
         g2 = g2 if g2.is_contiguous() else g2.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = linear_dgrad(g2, weight.contiguous()).view(*gy.shape[:-1], weight.shape[1])
+            wt = _transposed_for_dgrad(weight)
+            if wt is not None:
+                from . import hip
+                dx = hip.linear(g2, wt).view(*gy.shape[:-1], weight.shape[1])
+            else:
+                dx = linear_dgrad(g2, weight.contiguous()).view(*gy.shape[:-1], weight.shape[1])
         if ctx.needs_input_grad[1]:
             # an optimizer that keeps gradients in a flat buffer publishes the parameter's slot
             # as ``_grad_sink``: the first gradient of a step is written there by the GEMM itself

@@ -89,7 +89,8 @@ class VisionEngine:
         self._graphs: Dict[tuple, tuple] = {}
 
     # ------------------------------------------------------------------ forward
-    def _forward(self, px: torch.Tensor, pool: bool, n_temporal: Optional[int]) -> torch.Tensor:
+    def _forward(self, px: torch.Tensor, pool: bool, n_temporal: Optional[int],
+                 tower_only: bool = False) -> torch.Tensor:
         raw = self.raw
         T = px.shape[0]
         d, H, hd = self.cfg.hidden_size, self.heads, self.hd
@@ -108,6 +109,8 @@ class VisionEngine:
             y = raw.linear(y, l["w1"], l["b1"], None, self.act, False)
             x = raw.linear(y, l["w2"], l["b2"], x, 0, False)
         f = x
+        if tower_only:
+            return f
         for i, (w, b) in enumerate(self.proj):
             f = raw.linear(f, w, b, None, ACT_CODES["gelu"] if i + 1 < len(self.proj) else 0, False)
         if self.adaptor is not None:
@@ -117,30 +120,37 @@ class VisionEngine:
         return f
 
     @torch.no_grad()
-    def encode(self, frames, pool: bool = True, n_temporal: Optional[int] = None) -> torch.Tensor:
+    def encode(self, frames, pool: bool = True, n_temporal: Optional[int] = None,
+               tower_only: bool = False) -> torch.Tensor:
         """``frames``: ``[T,3,S,S]`` tensor or list of ``[3,S,S]``.  Returns pooled
-        ``[T'+N, hidden]`` (or per-frame ``[T, N, hidden]`` with ``pool=False``)."""
+        ``[T'+N, hidden]`` (or per-frame ``[T, N, hidden]`` with ``pool=False``).
+        ``tower_only``: stop after the (frozen) ViT blocks and return ``[T, N, vision_hidden]`` --
+        what a training step feeds its trainable projector."""
         if isinstance(frames, (list, tuple)):
             frames = torch.stack([f.to(self.device) for f in frames])
         px = frames.to(self.device, torch.bfloat16).contiguous()
         if not self.use_graph:
-            return self._forward(px, pool, n_temporal)
-        key = (tuple(px.shape), pool, n_temporal)
+            return self._forward(px, pool, n_temporal, tower_only)
+        key = (tuple(px.shape), pool, n_temporal, tower_only)
         entry = self._graphs.get(key)
         if entry is None:
             static_in = px.clone()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self._forward(static_in, pool, n_temporal)     # warm-up
+                self._forward(static_in, pool, n_temporal, tower_only)     # warm-up
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                static_out = self._forward(static_in, pool, n_temporal)
+                static_out = self._forward(static_in, pool, n_temporal, tower_only)
             entry = (g, static_in, static_out)
             self._graphs[key] = entry
         g, static_in, static_out = entry
         static_in.copy_(px)
         g.replay()
         return static_out.clone()
+
+    def encode_tower(self, frames) -> torch.Tensor:
+        """The frozen tower alone: ``[T, N, vision_hidden]`` (one graph replay)."""
+        return self.encode(frames, pool=False, tower_only=True)

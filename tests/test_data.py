@@ -161,3 +161,21 @@ def test_preprocess_matches_hf_clip_processor():
     got = torch.from_numpy(cp.preprocess_image(frame))
     assert got.shape == (3, 336, 336)
     assert (got - want).abs().max().item() < 1e-5
+
+
+def test_resample_table_vectorised_builder_equals_per_coordinate_form():
+    """The table builder that works on all output coordinates at once gives the same integer taps as
+    the one-coordinate-at-a-time specification (down- and up-scaling, tiny and odd sizes)."""
+    import random
+
+    import numpy as np
+
+    from eventgpt_amd.data import clip_preprocess as cp
+    rnd = random.Random(3)
+    sizes = [(640, 448), (480, 336), (336, 336), (346, 336), (260, 336), (1280, 597), (100, 336), (5, 336),
+             (337, 336)] + [(rnd.randint(20, 1500), rnd.randint(300, 700)) for _ in range(12)]
+    for n_in, n_out in sizes:
+        want = cp._resample_table_loop(n_in, n_out)
+        got = cp.resample_table(n_in, n_out)
+        assert np.array_equal(want.start, got.start) and np.array_equal(want.count, got.count), (n_in, n_out)
+        assert np.array_equal(want.weight, got.weight), (n_in, n_out)

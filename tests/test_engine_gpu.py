@@ -152,9 +152,10 @@ def test_vision_engine_matches_module_path(dev):
                                          image_size=56, patch_size=14)
     m = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=3)
     frames = (torch.randn(5, 3, 56, 56, device=dev)).to(torch.bfloat16)
-    feats = m.get_model().feature_adaptor(m.visval_encode(frames))
     from eventgpt_amd.models import get_spatio_temporal_features
-    want = get_spatio_temporal_features(feats)
+    with torch.no_grad():                           # the module path (a training step takes the engine's tower)
+        feats = m.get_model().feature_adaptor(m.visval_encode(frames))
+        want = get_spatio_temporal_features(feats)
     got = m.vision_engine().encode(frames)
     got2 = m.vision_engine().encode(frames)        # graph replay
     assert got.shape == (5 + 17, 512)
@@ -163,6 +164,17 @@ def test_vision_engine_matches_module_path(dev):
     assert err < 0.06, err
     one = m.vision_engine().encode(frames[:1])
     assert one.shape == (1 + 17, 512)
+    # a training step: frozen tower as one graph replay, projector + adaptor on autograd
+    tower = m.vision_engine().encode_tower(frames)
+    with torch.no_grad():
+        tower_want = m.get_model().visual_tower.visual_tower(frames).last_hidden_state
+    assert tower.shape == tower_want.shape == (5, 17, 256)
+    assert (tower.float() - tower_want.float()).abs().max().item() < 0.06
+    m.get_model().visual_projector.requires_grad_(True)
+    out = m.visval_encode(frames)
+    assert out.requires_grad and (out.float() - m.get_model().visual_projector(tower_want).float()).abs().max().item() < 0.06
+    out.float().pow(2).mean().backward()
+    assert all(p.grad is not None for p in m.get_model().visual_projector.parameters())
 
 
 @pytest.mark.parametrize("B", [3, 6])

@@ -82,6 +82,28 @@ def test_frozen_weight_skips_wgrad(dev):
     assert w.grad is None and x.grad is not None
 
 
+def test_frozen_weight_dgrad_through_transposed_copy(dev):
+    """Frozen matrices may carry a row-major copy of their transpose; the input gradient then runs the
+    plain GEMM on it.  Same numbers as the fp32 product, also after the weight is written in place."""
+    from eventgpt_amd.models.llama import Linear
+    from eventgpt_amd.ops.differentiable import enable_transposed_dgrad
+    lin = Linear(512, 1088, bias=False).to(dev, torch.bfloat16)
+    train = Linear(512, 64, bias=False).to(dev, torch.bfloat16)
+    lin.weight.requires_grad_(False)
+    mod = torch.nn.ModuleList([lin, train])
+    spent = enable_transposed_dgrad(mod, min_free_bytes=0)
+    assert spent == lin.weight.numel() * 2 and not hasattr(train.weight, "_dgrad_t")
+    g = _rand(836, 1088, dev=dev, seed=3)
+    for rnd in range(2):
+        x = _rand(836, 512, dev=dev, seed=2).requires_grad_(True)
+        lin(x).backward(g)
+        want = g.float() @ lin.weight.float()
+        _close(x.grad, want, 2e-2 * math.sqrt(1088 / 64), 2e-2)
+        assert torch.equal(lin.weight._dgrad_t[0], lin.weight.t())
+        with torch.no_grad():
+            lin.weight.mul_(0.5)        # the copy is stale now; the next backward refreshes it
+
+
 def _attn_ref_grads(q, k, v, go, causal, q_offset):
     qf, kf, vf = (t.detach().float().requires_grad_(True) for t in (q, k, v))
     rep = q.shape[2] // k.shape[2]          # grouped KV heads: the oracle takes them expanded
