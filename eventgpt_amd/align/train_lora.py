@@ -85,6 +85,11 @@ class LoRATrainer:
                 else:
                     torch.distributed.broadcast(p.data, 0)
         self.opt = ShardedAdamW(lora_parameters(model), lr=learning_rate, weight_decay=0.01, overlap=False)
+        # the frozen base matrices keep K-contiguous copies for the input-gradient GEMMs while the
+        # device has room for them (ops/differentiable.py)
+        if self.device.type == "cuda":
+            from ..ops.differentiable import enable_transposed_dgrad
+            enable_transposed_dgrad(model.model.layers)
         self.history: List[Dict] = []
         self.params = count_parameters(model)
 
