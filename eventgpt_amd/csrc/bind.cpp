@@ -168,8 +168,11 @@ Tensor linear_t(const Tensor& a, const Tensor& w, bool a_t, bool w_t, const c10:
   TORCH_CHECK(ka_rows >= 1 && kw_rows >= 1 && ka_rows <= K && kw_rows <= K && K - std::min(ka_rows, kw_rows) < 64,
               "linear_t: K is the contraction rounded up to 64");
   TORCH_CHECK(a.numel() < (1ll << 30) && w.numel() < (1ll << 30), "linear_t: operands < 2 GiB each");
-  TORCH_CHECK(ka_rows == K || kw_rows == K, "linear_t: one operand must cover the padded contraction (zero rows / "
-              "columns for k past the real length); the other may stop at the real length");
+  // K-strided operands end at their last row: the staging loads are range-checked against the rows that
+  // exist and return zeros past them.  A K-contiguous operand runs on into its next row instead, so it
+  // must carry the zero padding itself (0 x garbage is only 0 for finite garbage).
+  TORCH_CHECK((a_t && w_t) || ka_rows == K || kw_rows == K, "linear_t: with a K-contiguous operand, one operand must "
+              "cover the padded contraction (zero rows / columns for k past the real length)");
   if (bias.has_value()) { check_bf16(*bias, "bias"); TORCH_CHECK(bias->numel() == N); }
   if (res.has_value()) { check_bf16(*res, "residual"); TORCH_CHECK(res->numel() == M * N); }
   Tensor y;

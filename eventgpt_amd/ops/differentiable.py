@@ -121,10 +121,6 @@ def _pad_cols(t: torch.Tensor, k: int) -> torch.Tensor:
     return t if t.shape[1] == k else F.pad(t, (0, k - t.shape[1]))
 
 
-def _pad_rows(t: torch.Tensor, k: int) -> torch.Tensor:
-    return t if t.shape[0] == k else F.pad(t, (0, 0, 0, k - t.shape[0]))
-
-
 def linear_dgrad(gy: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """``dX [M,K] = dY [M,N] @ W [N,K]``: the contraction runs over W's ROWS, so W is the
     K-strided operand of the GEMM (read through transposing LDS loads, never copied)."""
@@ -136,14 +132,9 @@ def linear_wgrad(gy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] 
     """``dW [N,K] = dY^T [N,M] @ X [M,K]``: both operands are strided in the token dimension.
     ``out``: a contiguous bf16 ``[N,K]`` tensor the product is written into (an optimizer's
     flat gradient buffer), instead of a new tensor."""
-    m = gy.shape[0]
-    mp = _round64(m)
-    if mp != m:      # zero rows on the smaller operand; the other one's tail rows are re-read and multiplied by 0
-        if gy.shape[1] <= x.shape[1]:
-            gy = _pad_rows(gy, mp)
-        else:
-            x = _pad_rows(x, mp)
-    return _raw().linear_t(gy, x, True, True, None, None, 0, False, mp, out)
+    # the contraction runs to the next multiple of 64; both operands are K-strided, whose staging
+    # loads return zeros for the rows past the last token, so neither is padded
+    return _raw().linear_t(gy, x, True, True, None, None, 0, False, _round64(gy.shape[0]), out)
 
 
 def enable_transposed_dgrad(module: torch.nn.Module, min_free_bytes: int = 32 << 30) -> int:
