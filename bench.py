@@ -18,7 +18,8 @@ A *step* is one decode step (one new token per stream).
   tensor-parallel (``parallel/tp.py``): the SAME single stream is served by N GPUs -- strong
   scaling, every decode step crosses 64 all-reduces -- and ``value`` is its tokens/s.  The
   batched configuration (32 event streams on the same TP group) is measured in the same run
-  and reported under ``tp_batch32``.  ``--parallelism dp`` (independent replicas, no
+  and reported under ``tp_batch32``, and so are N independent replicas (``dp_replicas``: no
+  communication in the step, the fabric-free bound).  ``--parallelism dp`` (independent replicas, no
   communication in the step) is available but is never the default: its curve says nothing
   about the fabric.
 
@@ -64,11 +65,16 @@ def parse_args(argv=None):
                     help="event streams decoded together per engine (32 = the batched serving config)")
     ap.add_argument("--no-batch32", action="store_true",
                     help="multi-GPU tp runs: skip the additional 32-stream measurement")
+    ap.add_argument("--no-dp-extra", action="store_true",
+                    help="multi-GPU tp runs: skip the additional independent-replicas measurement")
     ap.add_argument("--nsplit", type=int, default=None, help="KV splits of the decode attention")
     ap.add_argument("--allreduce", choices=["rccl", "oneshot", "auto"], default=None,
                     help="tensor-parallel collective (default: EVGPT_TP_ALLREDUCE or rccl)")
     ap.add_argument("--weight-format", choices=["bf16", "nf4", "fp4"], default="bf16",
                     help="nf4/fp4: the reference's 4-bit rows (bitsandbytes load_in_4bit); not the headline config")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="run the multi-rank flow on ONE GPU: every rank drives cuda:0 and the group is gloo "
+                         "(host-copied collectives, no graphs); exercises the code path, measures nothing useful")
     ap.add_argument("--probe", action="store_true",
                     help="launcher check: every rank joins a CPU (gloo) group, all-reduces a one and rank 0 "
                          "prints the world size; no GPU is touched")
@@ -173,7 +179,8 @@ def timed_decode(args, engine, embeds, batch: int, dist, dev):
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        # (a gloo group, the one-GPU rehearsal, is given host tensors only)
+        t = torch.tensor([dt], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if getattr(engine, "oneshot", None) is not None:
@@ -194,16 +201,20 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.rehearsal else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     rccl_world = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-        ones = torch.ones(1, device=dev)
-        dist.all_reduce(ones)                      # the collective really spans `world` GPUs
+        if args.rehearsal:
+            dist.init_process_group("gloo")
+            ones = torch.ones(1)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+            ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                      # the collective really spans `world` ranks
         rccl_world = int(ones.item())
 
     from eventgpt_amd.data import EventImageProcessor, event_frames, synthetic_events
@@ -263,18 +274,39 @@ def main(argv=None):
     graph_fallback = engine.graph_fallback
     tp_allreduce = getattr(engine, "allreduce_kind", "none")
 
-    # ---- the batched TP configuration (32 event streams), same group, same run
+    # ---- the batched TP configuration (32 event streams), same group, same run.  Extras never
+    # cost the headline line: a failure is reported under the key instead of raised (every rank
+    # takes the same branch, so the group stays in step).
     extra = {}
     if tp and args.batch == 1 and not args.no_batch32:
-        del engine, model
+        engine = model = None
         torch.cuda.empty_cache()
-        _, model32, _ = build_model(args, dev)
-        eng32 = build_engine(args, model32, dist, True, 32)
-        dt32 = timed_decode(args, eng32, embeds, 32, dist, dev)
-        extra["tp_batch32"] = {"tokens_per_s": round(32 * args.steps / dt32, 2),
-                               "ms_per_step": round(dt32 * 1e3 / args.steps, 4), "global_batch": 32,
-                               "graph_captured": bool(eng32.graph_captured),
-                               "tp_allreduce": getattr(eng32, "allreduce_kind", "none")}
+        try:
+            _, model32, _ = build_model(args, dev)
+            eng32 = build_engine(args, model32, dist, True, 32)
+            dt32 = timed_decode(args, eng32, embeds, 32, dist, dev)
+            extra["tp_batch32"] = {"tokens_per_s": round(32 * args.steps / dt32, 2),
+                                   "ms_per_step": round(dt32 * 1e3 / args.steps, 4), "global_batch": 32,
+                                   "graph_captured": bool(eng32.graph_captured),
+                                   "tp_allreduce": getattr(eng32, "allreduce_kind", "none")}
+        except Exception as e:
+            extra["tp_batch32"] = {"error": str(e)[:200]}
+        eng32 = model32 = None
+    # ---- independent replicas on the same GPUs (no communication in the step): the fabric-free
+    # bound the tensor-parallel numbers can be read against.  An extra key, never the value.
+    if tp and args.batch == 1 and not args.no_dp_extra:
+        engine = model = None
+        torch.cuda.empty_cache()
+        try:
+            _, model_dp, _ = build_model(args, dev)
+            eng_dp = build_engine(args, model_dp, None, False, 1)
+            dt_dp = timed_decode(args, eng_dp, embeds, 1, dist, dev)
+            extra["dp_replicas"] = {"tokens_per_s": round(world * args.steps / dt_dp, 2),
+                                    "ms_per_step": round(dt_dp * 1e3 / args.steps, 4), "global_batch": world,
+                                    "scaling": "weak", "graph_captured": bool(eng_dp.graph_captured)}
+        except Exception as e:
+            extra["dp_replicas"] = {"error": str(e)[:200]}
+        eng_dp = model_dp = None
     if rank == 0:
         print(json.dumps({
             "metric": "decode tokens/sec (EventGPT-7B bf16 greedy, bs 1 per stream)" if args.batch == 1
@@ -290,7 +322,8 @@ def main(argv=None):
             "event_prefill_vs_baseline": round(BASELINE_PREFILL_MS / prefill_ms, 3),
             "vision_ms_per_frame": round(vision_ms / args.frames, 3),
             "vision_vs_baseline": round(BASELINE_VISION_MS / (vision_ms / args.frames), 3),
-            "rccl_world_size": rccl_world, "graph_captured": graph_captured,
+            "rccl_world_size": rccl_world, **({"rehearsal_backend": "gloo"} if args.rehearsal else {}),
+            "graph_captured": graph_captured,
             "graph_fallback": graph_fallback, "tp_allreduce": tp_allreduce,
             **extra,
             "config": {"model": model_name, "global_batch": streams, "seq_len": S,

@@ -52,3 +52,25 @@ def test_single_gpu_default_does_not_launch():
     cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "5"], 29999)
     assert "--nproc-per-node=8" in cmd and cmd[-4:] == ["--gpus", "8", "--steps", "5"]
     assert "127.0.0.1" in cmd
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(420)
+@pytest.mark.parametrize("n", [2, 8])
+def test_multi_rank_flow_rehearsal_on_one_gpu(n):
+    """The whole multi-rank bench flow -- launcher, tensor-parallel engine, the 32-stream run and the
+    independent replicas, the MAX over ranks, one JSON line -- with the ranks sharing GPU 0 over gloo.
+    Eight ranks is the shape of the node the scaling runs use."""
+    env = _clean_env()
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    print(f"launching the {n}-rank rehearsal", flush=True)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--model", "small", "--rehearsal", "--steps", "4",
+                        "--warmup", "2", "--max-len", "1024"], env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    got = json.loads(lines[0])
+    assert got["n_gpus"] == n and got["rccl_world_size"] == n and got["scaling"] == "strong"
+    assert got["value"] > 0 and got["config"]["parallelism"] == f"tp{n}" and got["tp_allreduce"] == "gloo"
+    assert "error" not in got["tp_batch32"] and got["tp_batch32"]["tokens_per_s"] > 0, got["tp_batch32"]
+    assert "error" not in got["dp_replicas"] and got["dp_replicas"]["global_batch"] == n, got["dp_replicas"]
