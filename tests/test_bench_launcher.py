@@ -56,11 +56,11 @@ def test_single_gpu_default_does_not_launch():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(420)
-@pytest.mark.parametrize("n", [2, 8])
+@pytest.mark.parametrize("n", [2, 4])
 def test_multi_rank_flow_rehearsal_on_one_gpu(n):
     """The whole multi-rank bench flow -- launcher, tensor-parallel engine, the 32-stream run and the
     independent replicas, the MAX over ranks, one JSON line -- with the ranks sharing GPU 0 over gloo.
-    Eight ranks is the shape of the node the scaling runs use."""
+    The 8-rank case belongs to the scaling runs on the 8-GPU node and is not started from here."""
     env = _clean_env()
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     print(f"launching the {n}-rank rehearsal", flush=True)
