@@ -32,8 +32,12 @@ class LoRALinear(nn.Module):
         super().__init__()
         self.base = base
         self.r, self.alpha, self.scaling = r, alpha, alpha / r
-        self.lora_A = nn.Linear(base.in_features, r, bias=False, device=base.weight.device, dtype=base.weight.dtype)
-        self.lora_B = nn.Linear(r, base.out_features, bias=False, device=base.weight.device, dtype=base.weight.dtype)
+        # the framework's Linear (an nn.Linear whose forward / dgrad / wgrad run the in-tree MFMA
+        # GEMM on bf16 GPU tensors): as plain nn.Linear the two low-rank products of every wrapped
+        # layer -- and their backward -- were 128 library GEMM launches per step at 7B
+        from ..models.llama import Linear
+        self.lora_A = Linear(base.in_features, r, bias=False, device=base.weight.device, dtype=base.weight.dtype)
+        self.lora_B = Linear(r, base.out_features, bias=False, device=base.weight.device, dtype=base.weight.dtype)
         nn.init.kaiming_uniform_(self.lora_A.weight, a=math.sqrt(5))
         nn.init.zeros_(self.lora_B.weight)
         self.lora_dropout = nn.Dropout(dropout) if dropout > 0 else nn.Identity()
