@@ -727,6 +727,14 @@ int gemm_splitk(int M, int N, int K) {
     const GemmCfg cfg = pick_cfg(M, N, K);
     const long long tl = cfg_tiles(cfg, M, N);
     int s = 1;   // fill the co-resident slots (2 blocks of 128x128, 3 of 64x128 per CU)
+    if (tl <= 32 && K >= 2048) {
+      // a narrow output over a long contraction (low-rank projections: hundreds of rows into 16
+      // columns) is a few dozen blocks walking the whole K: split until the grid is a few hundred
+      // blocks, keeping >= 4 K-steps per split
+      const long long want = 256 / tl, most = K / 256;
+      s = static_cast<int>(want < most ? want : most);
+      return s < 1 ? 1 : (s > 16 ? 16 : s);
+    }
     if (cfg == CFG_128x128 && K >= 8192 && tl >= 96 && tl < 256) s = static_cast<int>(512 / tl);
     else if (cfg == CFG_64x128 && K >= 4096 && tl >= 48 && tl < 128) s = static_cast<int>(256 / tl);
     return s < 1 ? 1 : (s > 4 ? 4 : s);
@@ -812,7 +820,13 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
 int gemm_splitk_t(int M, int N, int K) {
   if (g_forced_splitk > 0) return (K / 64) >= g_forced_splitk ? g_forced_splitk : 1;
   const long long t = static_cast<long long>((M + 127) / 128) * ((N + 127) / 128);
-  if (M > 1024 || K < 8192 || t < 96 || t >= 256 || g_forced_cfg >= 0) return 1;
+  if (g_forced_cfg >= 0 || M > 1024) return 1;
+  if (t <= 32 && K >= 2048) {   // narrow output, long contraction (input gradient of a low-rank B): as in gemm_splitk
+    const long long want = 256 / t, most = K / 256;
+    const int s = static_cast<int>(want < most ? want : most);
+    return s < 1 ? 1 : (s > 16 ? 16 : s);
+  }
+  if (K < 8192 || t < 96 || t >= 256) return 1;
   const int s = static_cast<int>(512 / t);
   return s < 1 ? 1 : (s > 4 ? 4 : s);
 }
