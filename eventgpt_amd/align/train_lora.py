@@ -131,8 +131,13 @@ class LoRATrainer:
         m = self.model
         with torch.no_grad():
             px = inp["pixel_values"].to(self.device, m.dtype)
-            feats = m.get_model().feature_adaptor(m.visval_encode(px[None]))[0]
-            feats = get_spatio_temporal_features([feats])[None].detach()
+            if px.is_cuda and m.dtype == torch.bfloat16:
+                # tower, projector, adaptor and pooling are all frozen here: one replay of the serving
+                # engine's captured launch sequence instead of ~300 eager launches
+                feats = m.encode_event_frames([px])[None].detach()
+            else:
+                feats = m.get_model().feature_adaptor(m.visval_encode(px[None]))[0]
+                feats = get_spatio_temporal_features([feats])[None].detach()
         ids = torch.cat([inp["input_ids"], inp["gen_token_ids"][None]], 1).to(self.device)
         embeds = m.prepare_inputs_labels_for_multimodal(
             ids, None, None, None, None, event_features=feats, event_image_sizes=[inp["event_image_size"]],
