@@ -20,6 +20,7 @@ What is different here:
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import time
@@ -44,7 +45,8 @@ class HiddenAdapterTrainer:
     def __init__(self, model, train_loader, val_loader=None, learning_rate: float = 1e-3,
                  weight_decay: float = 0.01, device="cuda", vlm_only: bool = False,
                  fused: bool = False, num_epochs: int = 100, info: Optional[DistInfo] = None,
-                 autocast: Optional[bool] = None, bucket_bytes: int = 64 << 20):
+                 autocast: Optional[bool] = None, bucket_bytes: int = 64 << 20, intree_gemm: bool = True):
+        self.intree_gemm, self.linear_mode = intree_gemm, None
         self.info = info or DistInfo(device=torch.device(device))
         self.device = torch.device(device)
         self.model = model.to(self.device)
@@ -69,8 +71,16 @@ class HiddenAdapterTrainer:
         return src, tgt, batch["mask"].to(self.device, non_blocking=nb)
 
     def _ctx(self):
-        return torch.autocast("cuda", dtype=torch.bfloat16) if self.autocast else \
-            torch.autocast("cpu", enabled=False)
+        """bf16 autocast on a GPU, with the adapter's ``nn.Linear`` layers on the in-tree GEMM
+        (``ops/intree_mode.py``) unless ``intree_gemm`` is off."""
+        if not self.autocast:
+            return torch.autocast("cpu", enabled=False)
+        stack = contextlib.ExitStack()
+        stack.enter_context(torch.autocast("cuda", dtype=torch.bfloat16))
+        if self.intree_gemm:
+            from ..ops.intree_mode import InTreeLinear
+            self.linear_mode = stack.enter_context(InTreeLinear())
+        return stack
 
     def _mean_over_ranks(self, total: float, count: float) -> float:
         t = all_reduce_scalar(total, device=self.device)
@@ -251,6 +261,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--resume", type=str, default=None, help="task directory to continue")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--cpu", action="store_true")
+    p.add_argument("--library_gemm", action="store_true",
+                   help="leave the adapter's nn.Linear layers on the vendor GEMM library (default: in-tree GEMM)")
     return p
 
 
@@ -311,7 +323,7 @@ def main(argv=None) -> str:
     os.makedirs(save_dir, exist_ok=True)
     trainer = HiddenAdapterTrainer(model, train_loader, val_loader, args.learning_rate,
                                    device=info.device, vlm_only=args.vlm_only,
-                                   num_epochs=args.num_epochs, info=info)
+                                   num_epochs=args.num_epochs, info=info, intree_gemm=not args.library_gemm)
     if args.resume and trainer.resume(save_dir) and info.is_main:
         print(f"resumed from {save_dir} at epoch {trainer.start_epoch}")
     if info.is_main:

@@ -117,3 +117,34 @@ def test_verify_past_the_cache_is_refused(dev):
     with pytest.raises(ValueError, match="does not fit the cache"):
         v.verify(draft, 5)
     assert int(v.pos[0]) <= 64
+
+
+@pytest.mark.parametrize("level", [1, 3])
+def test_adapter_training_step_on_in_tree_linear(level):
+    """Inside ``InTreeLinear`` the nn.Linear layers of an adapter (fp32 parameters, bf16 autocast) run
+    the in-tree GEMM forward and backward; loss and parameter gradients agree with the library path."""
+    from eventgpt_amd.align.adapters import create_adapter
+    from eventgpt_amd.ops.intree_mode import InTreeLinear
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    a = create_adapter(level, 512, bottleneck_dim=64).to(dev)
+    b = create_adapter(level, 512, bottleneck_dim=64).to(dev)
+    b.load_state_dict(a.state_dict())
+    a.eval(), b.eval()                       # no dropout: the two paths see the same function
+    h = torch.randn(8, 40, 512, device=dev)
+    t = h + 0.1 * torch.randn_like(h)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        la = a.compute_loss(h, t)["total_loss"]
+    with torch.autocast("cuda", dtype=torch.bfloat16), InTreeLinear() as mode:
+        lb = b.compute_loss(h, t)["total_loss"]
+    assert mode.routed >= 2, (mode.routed, mode.passed)
+    la.backward()
+    lb.backward()
+    assert abs(float(la) - float(lb)) < 2e-2 * abs(float(la)) + 1e-4
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pa.grad is None:
+            assert pb.grad is None, n
+            continue
+        assert pb.grad is not None and pb.grad.dtype == torch.float32, n
+        err = (pa.grad - pb.grad).abs().max().item()
+        assert err < 3e-2 * pa.grad.abs().max().item() + 1e-6, (n, err)
