@@ -122,6 +122,29 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 8, extra: str 
     return out
 
 
+def build_tools(verbose: bool = False) -> list:
+    """Stand-alone HIP programs of ``benchmarks/hip`` (timing probes with their own ``main``): one
+    hipcc call each, next to their source, rebuilt when the source or the shared header is newer."""
+    root = os.path.dirname(PKG_DIR)
+    outs = []
+    for src in sorted(glob.glob(os.path.join(root, "benchmarks", "hip", "*.hip"))):
+        out = src[:-4]
+        deps = [src, os.path.join(CSRC, "kernels", "common.h")]
+        if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+            outs.append(out)
+            continue
+        flags = [f for f in HIP_FLAGS if f != "-fPIC"]
+        cmd = [_hipcc(), *flags, src, "-o", out]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError(f"hipcc failed on {src}")
+        outs.append(out)
+    return outs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
