@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     for (int i = 0; i < LD_PER_THREAD; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / CPR, ch = idx % CPR;
-      *reinterpret_cast<u32x4_t*>(k_lds + tile_off_k<D>(row, ch)) = kr[i];
+      *reinterpret_cast<u32x4_t*>(k_lds + tile_off<D>(row, ch)) = kr[i];
       *reinterpret_cast<u32x4_t*>(v_lds + tile_off<D>(row, ch)) = vr[i];
     }
   };
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(
-            k_lds + tile_off_k<D>(n * 16 + fr, ks * 4 + g));
+            k_lds + tile_off<D>(n * 16 + fr, ks * 4 + g));
         st[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[n], 0, 0, 0);
       }
 
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_prefill_wide_kernel(AttnPa
 #pragma unroll
   for (int j = 0; j < NIW; ++j) {
     const int idx = (wid * NIW + j) * 64 + lane;
-    const int row = idx / CPR, ch = (idx % CPR) ^ swz<D>(row), ch_k = (idx % CPR) ^ swz_k<D>(row);
-    voff_k[j] = static_cast<int>((row * p.k_ss + ch_k * 8) * 2);
+    const int row = idx / CPR, ch = (idx % CPR) ^ swz<D>(row);
+    voff_k[j] = static_cast<int>((row * p.k_ss + ch * 8) * 2);
     voff_v[j] = static_cast<int>((row * p.v_ss + ch * 8) * 2);
   }
   auto stage = [&](int buf, int t) {
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_prefill_wide_kernel(AttnPa
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(k_lds + tile_off_k<D>(n * 16 + fr, ks * 4 + g));
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(k_lds + tile_off<D>(n * 16 + fr, ks * 4 + g));
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
           st[qt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[qt][n], 0, 0, 0);
