@@ -355,6 +355,66 @@ class TensorParallelEngine(GenerationEngine):
             x = self._reduce(raw.linear(h, l.w_down, None, x if lead else None, 0, False))
         return x
 
+    #: most rows one packed prefill pass carries (bounds the [rows, 3H] / [rows, 2I] temporaries)
+    PACK_ROWS = 8192
+
+    def _forward_rows_packed(self, embeds_list: Sequence[torch.Tensor], slots: Sequence[int]) -> List[torch.Tensor]:
+        """Prefill several fresh sequences in ONE pass: the projections run over all prompts' rows
+        together (four 636-token prompts are a 2544-row GEMM, which runs the 8-wave kernel, instead
+        of four 636-row ones), RoPE / cache append and attention stay per prompt (each slot has its
+        own cache rows).  Returns the final hidden state of each prompt's last token."""
+        raw = self.raw
+        lens = [int(e.shape[0]) for e in embeds_list]
+        T = sum(lens)
+        offs = [0]
+        for n in lens:
+            offs.append(offs[-1] + n)
+        x = torch.cat([e.to(torch.bfloat16) for e in embeds_list]).contiguous().view(1, T, self.H)
+        lens_d = torch.tensor(lens, dtype=torch.int32, device=self.device)
+        pos0 = torch.zeros(1, dtype=torch.int32, device=self.device)
+        q = torch.empty(T, self.Hq, self.D, dtype=torch.bfloat16, device=self.device)
+        o = torch.empty_like(q)
+        lead = self.tp_rank == 0
+        for l in self.layers:
+            qkv = raw.linear(raw.rmsnorm(x, l.norm1, self.eps), l.w_qkv, None, None, 0, False).view(T, -1)
+            for i, b in enumerate(slots):
+                a, e = offs[i], offs[i + 1]
+                kc, vc = l.k_cache[b:b + 1], l.v_cache[b:b + 1]
+                qi, oi = q[a:e].view(1, e - a, self.Hq, self.D), o[a:e].view(1, e - a, self.Hq, self.D)
+                raw.prefill_rope_kv(qkv[a:e].view(1, e - a, -1), qi, kc, vc, self.cos, self.sin, pos0,
+                                    self.Hq, self.Hkv, self.D)
+                raw.attention_cache(qi, kc, vc, oi, lens_d[i:i + 1], self.scale)
+            x = self._reduce(raw.linear(o.view(1, T, self.Hq * self.D), l.w_o, None, x if lead else None, 0, False))
+            h = self._mlp_up(raw.rmsnorm(x, l.norm2, self.eps), l.w_gate_up)
+            x = self._reduce(raw.linear(h, l.w_down, None, x if lead else None, 0, False))
+        return [x[0, offs[i + 1] - 1] for i in range(len(slots))]
+
+    def _prefill_slots(self, slots: Sequence[int], embeds_list: Sequence[torch.Tensor]) -> None:
+        """Fill the caches of ``slots`` from their prompts and stage each last hidden state for the
+        commit: prompts are packed into passes of at most ``PACK_ROWS`` rows; a pass of one prompt
+        (or prompts short enough for the few-row kernels) takes the single-sequence path."""
+        for emb in embeds_list:
+            if emb.shape[0] > self.l_max:
+                raise ValueError(f"prompt of {emb.shape[0]} tokens exceeds the cache ({self.l_max})")
+        i, n = 0, len(slots)
+        while i < n:
+            j, rows = i, 0
+            while j < n and (j == i or rows + embeds_list[j].shape[0] <= self.PACK_ROWS):
+                rows += int(embeds_list[j].shape[0])
+                j += 1
+            group_s, group_e = list(slots[i:j]), list(embeds_list[i:j])
+            if j - i >= 2 and min(int(e.shape[0]) for e in group_e) > 32:
+                lasts = self._forward_rows_packed(group_e, group_s)
+            else:
+                lasts = []
+                for b, emb in zip(group_s, group_e):
+                    pos0 = torch.zeros(1, dtype=torch.int32, device=self.device)
+                    lasts.append(self._forward_rows(emb, b, pos0)[0, -1])
+            for b, emb, last in zip(group_s, group_e, lasts):
+                self.x[b].copy_(last)
+                self.pos[b] = emb.shape[0] - 1      # the commit advances it to the prompt length
+            i = j
+
     def _layers_step(self) -> None:
         raw = self.raw
         if self.B <= 3:     # measured: the GEMV holds up to 3 rows (3.09 / 3.75 ms), 4 rows are faster as a GEMM
@@ -444,11 +504,7 @@ class TensorParallelEngine(GenerationEngine):
         if len(embeds_list) != self.B:
             raise ValueError(f"need {self.B} prompts, got {len(embeds_list)}")
         self.reset()
-        for b, emb in enumerate(embeds_list):
-            pos0 = torch.zeros(1, dtype=torch.int32, device=self.device)
-            h = self._forward_rows(emb, b, pos0)
-            self.x[b].copy_(h[0, -1])
-            self.pos[b] = emb.shape[0] - 1      # the commit advances it to the prompt length
+        self._prefill_slots(list(range(self.B)), list(embeds_list))
         self._logits_and_commit(greedy=True)
 
     def prefill(self, embeds, batch: int = 0, start: Optional[int] = None,
@@ -477,15 +533,9 @@ class TensorParallelEngine(GenerationEngine):
         if len(slots) != len(embeds_list) or not slots:
             raise ValueError("one prompt per admitted slot")
         keep = self.active.clone()
-        for b, emb in zip(slots, embeds_list):
-            if emb.shape[0] > self.l_max:
-                raise ValueError(f"prompt of {emb.shape[0]} tokens exceeds the cache ({self.l_max})")
-            pos0 = torch.zeros(1, dtype=torch.int32, device=self.device)
-            h = self._forward_rows(emb, b, pos0)
-            self.x[b].copy_(h[0, -1])
-            self.pos[b] = emb.shape[0] - 1      # the commit advances it to the prompt length
-            self.step[b] = 0
-            self.done[b] = 0
+        self._prefill_slots(list(slots), list(embeds_list))
+        self.step[list(slots)] = 0
+        self.done[list(slots)] = 0
         self.active.zero_()
         self.active[list(slots)] = 1
         self._logits_and_commit(greedy=True)

@@ -6,8 +6,10 @@ sequence's position, step counter, EOS flag and token ring in device memory and 
 all slots with ONE captured decode graph per step.  The scheduler only edits the per-slot
 ``active`` mask that the commit kernel reads:
 
-  * a waiting request is admitted into a free slot: its prompt is prefilled into that
-    slot's cache rows and its first token is committed with every other slot masked out;
+  * waiting requests are admitted into free slots, up to ``max_admit_per_step`` at a time: their
+    prompts are prefilled as ONE pack (the projections run over all their rows together, RoPE /
+    cache append / attention per slot) and their first tokens are committed with every other slot
+    masked out;
   * every step replays the graph; finished slots (EOS or token budget) are parked, their
     tokens handed to the request, and the slot is free for the next admission;
   * the host reads ``step``/``done``/new tokens once every ``poll_every`` steps, so the
@@ -45,7 +47,7 @@ class Request:
 
 
 class ContinuousBatcher:
-    def __init__(self, engine, eos_token_id: int = 2, poll_every: int = 8, max_admit_per_step: int = 4):
+    def __init__(self, engine, eos_token_id: int = 2, poll_every: int = 8, max_admit_per_step: int = 8):
         if not hasattr(engine, "admit"):
             raise TypeError("ContinuousBatcher needs a multi-slot engine (TensorParallelEngine)")
         self.e = engine

@@ -197,6 +197,46 @@ def test_batched_engine_matches_single_stream(model, dev, B):
         assert_lossless(single, prompts[b], eng.tokens(b).long(), want[b])
 
 
+def test_packed_prefill_of_several_prompts(model, dev):
+    """Prompts of more than 32 tokens admitted together share one set of projections (their rows are
+    concatenated) with per-prompt RoPE / cache append / attention: every stream still reproduces its
+    own greedy decode, whether the prompts go in one pack, in several, or a pack holds one prompt."""
+    from _lossless import assert_lossless
+    from eventgpt_amd.parallel.tp import TensorParallelEngine
+    lens = [40, 77, 130, 64, 171]
+    prompts = [(torch.randn(n, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(n))
+                * 0.5).to(torch.bfloat16) for n in lens]
+    single = model.engine(max_len=512, max_new_tokens=64)
+    want = [single.generate(p, 8, eos_token_id=-1) for p in prompts]
+    for pack_rows, expect_calls in ((8192, 1), (250, 2)):      # 250: [40, 77, 130] [64, 171]
+        eng = TensorParallelEngine(model, None, max_len=256, max_batch=len(lens), max_new_tokens=32)
+        eng.eos = -1
+        eng.PACK_ROWS = pack_rows
+        calls = []
+        inner = eng._forward_rows_packed
+        eng._forward_rows_packed = lambda e, s: (calls.append(len(s)), inner(e, s))[1]
+        eng.prefill_batch(prompts)
+        assert len(calls) == expect_calls, calls
+        for _ in range(7):
+            eng.decode_step(True)
+        for b in range(len(lens)):
+            assert_lossless(single, prompts[b], eng.tokens(b).long(), want[b])
+    # admission into a running batch: two slots keep decoding, three new prompts arrive packed
+    eng = TensorParallelEngine(model, None, max_len=256, max_batch=5, max_new_tokens=32)
+    eng.eos = -1
+    eng.enable_slot_masks()
+    eng.reset()
+    eng.active.zero_()
+    eng.admit([0, 1], prompts[:2])
+    for _ in range(3):
+        eng.decode_step(True)
+    eng.admit([2, 3, 4], prompts[2:])
+    for _ in range(7):
+        eng.decode_step(True)
+    for b in range(5):
+        assert_lossless(single, prompts[b], eng.tokens(b).long()[:8], want[b])
+
+
 @pytest.mark.timeout(300)
 def test_tensor_parallel_engine_two_ranks(tmp_path):
     """Sharded serving engine on real kernels: two processes (gloo, both on GPU 0) must
