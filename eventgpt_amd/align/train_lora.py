@@ -256,6 +256,9 @@ class LoRATrainer:
                            "token_loss_weight": self.token_loss_weight, "event_image_key": self.key,
                            "world_size": self.info.world, "best_metric": best,
                            "created": datetime.now().isoformat()}, f, indent=2)
+        if self.device.type == "cuda":
+            from ..ops.differentiable import release_transposed_dgrad
+            release_transposed_dgrad(self.model)
         return {"history": self.history, "best": best}
 
 

@@ -260,6 +260,10 @@ class SFTTrainer:
             if save_every_epoch:
                 self.save_state(epoch)
         pool.shutdown(wait=True)
+        if self.dgrad_copy_bytes:               # training is over: hand the frozen matrices' copies back
+            from ..ops.differentiable import release_transposed_dgrad
+            release_transposed_dgrad(self.model)
+            self.dgrad_copy_bytes = 0
         paths = self.save_outputs()
         if info.is_main:
             with open(os.path.join(self.out, "history.json"), "w") as f:

@@ -161,6 +161,18 @@ def enable_transposed_dgrad(module: torch.nn.Module, min_free_bytes: int = 32 <<
     return spent
 
 
+def release_transposed_dgrad(module: torch.nn.Module) -> int:
+    """Drop the copies ``enable_transposed_dgrad`` made (after training: they are one more copy of
+    every frozen matrix).  Returns the bytes released."""
+    freed = 0
+    for p in module.parameters():
+        ent = getattr(p, "_dgrad_t", None)
+        if ent is not None:
+            freed += ent[0].numel() * ent[0].element_size()
+            del p._dgrad_t
+    return freed
+
+
 def _transposed_for_dgrad(weight) -> Optional[torch.Tensor]:
     ent = getattr(weight, "_dgrad_t", None)
     if ent is None or weight.requires_grad:

@@ -102,6 +102,8 @@ def test_frozen_weight_dgrad_through_transposed_copy(dev):
         assert torch.equal(lin.weight._dgrad_t[0], lin.weight.t())
         with torch.no_grad():
             lin.weight.mul_(0.5)        # the copy is stale now; the next backward refreshes it
+    from eventgpt_amd.ops.differentiable import release_transposed_dgrad
+    assert release_transposed_dgrad(mod) == spent and not hasattr(lin.weight, "_dgrad_t")
 
 
 def _attn_ref_grads(q, k, v, go, causal, q_offset):
