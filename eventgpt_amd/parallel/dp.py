@@ -220,6 +220,9 @@ class ShardedAdamW:
         return sq
 
     def global_grad_norm(self) -> float:
+        """Norm of the (averaged) gradient as a host number.  Settles and reduces the buckets
+        first, which ``step()`` would do anyway and which is idempotent."""
+        self._finish_reduces()
         return float(self._global_sq_norm().sqrt())
 
     def _gather(self, b: _Bucket, new_shard: torch.Tensor) -> None:
