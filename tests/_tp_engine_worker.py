@@ -44,6 +44,9 @@ def run_config(model_fn, info, prompts, want_x, allreduce):
     eng = TensorParallelEngine(model_fn(), dist.group.WORLD, max_len=256, max_batch=B, max_new_tokens=32,
                                use_graph=False, allreduce=allreduce)
     eng.eos = -1
+    packed = []
+    inner = eng._forward_rows_packed
+    eng._forward_rows_packed = lambda e, s: (packed.append(len(s)), inner(e, s))[1]
     eng.prefill_batch(prompts)
     first_tok = [int(eng.out_tokens[b, 0]) for b in range(B)]
     c0 = [float(cos(eng.x[b].float(), want_x[b][0], dim=0)) for b in range(B)]
@@ -67,7 +70,7 @@ def run_config(model_fn, info, prompts, want_x, allreduce):
     res = {"ranks": [g[0] for g in gathered], "timeouts": [g[1] for g in gathered], "first_tok": first_tok,
            "cos_prefill": c0, "cos_step": c1, "heads_local": eng.Hq, "i_local": eng.I,
            "logits_width": int(eng.logits.shape[1]), "logits_equal": all(r == rows[0] for r in rows),
-           "allreduce_kind": eng.allreduce_kind}
+           "allreduce_kind": eng.allreduce_kind, "packed_prompts": sum(packed)}
     if eng.oneshot is not None:
         eng.oneshot.close()
     return res
@@ -85,7 +88,10 @@ def main(out_path):
     model_fn = lambda: EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=3)   # noqa: E731
     out = {}
     for B in (2, 6):
-        prompts = [(torch.randn(20 + 3 * b, H, device=dev, generator=torch.Generator(device=dev).manual_seed(b))
+        # two streams: short prompts, prefilled one by one; six streams: every prompt longer than 32
+        # tokens, so they are prefilled as ONE pack (shared projections, per-slot attention)
+        base = 20 if B == 2 else 40
+        prompts = [(torch.randn(base + 3 * b, H, device=dev, generator=torch.Generator(device=dev).manual_seed(b))
                     * 0.5).to(torch.bfloat16) for b in range(B)]
         want, want_x = reference(model_fn(), prompts)
         print(f"rank {info.rank}: single-engine reference for {B} streams done", flush=True)

@@ -262,6 +262,7 @@ def test_tensor_parallel_engine_two_ranks(tmp_path):
         assert got["heads_local"] == 2 and got["i_local"] == 704 and got["logits_width"] == 515, key
         assert got["allreduce_kind"] == ("oneshot" if key.endswith("oneshot") else "gloo"), key
         assert got["timeouts"] == [0, 0], (key, got["timeouts"])
+        assert got["packed_prompts"] == (6 if key.startswith("b6") else 0), (key, got["packed_prompts"])
         assert got["ranks"][0] == got["ranks"][1], key          # the ranks agree token for token
         assert got["logits_equal"], key
         # same first token, and the residual stream after one more step of layers agrees with
@@ -300,6 +301,7 @@ def test_tensor_parallel_engine_more_ranks(tmp_path, world):
         got = allgot[key]
         assert got["heads_local"] == 1 and got["i_local"] == i_local and got["logits_width"] == 515, (key, got["i_local"])
         assert len(got["ranks"]) == world and all(rk == got["ranks"][0] for rk in got["ranks"]), key
+        assert got["packed_prompts"] == (6 if key.startswith("b6") else 0), (key, got["packed_prompts"])
         assert got["logits_equal"], key
         for b, want in enumerate(got["want"]):
             assert got["first_tok"][b] == want[0] == got["ranks"][0][b][0], (key, b)
