@@ -147,12 +147,15 @@ def build_engine(args, model, dist, tp: bool, batch: int):
     if args.weight_format != "bf16":
         ekw["weight_format"] = args.weight_format
     budget = args.steps + args.warmup + 8
+    # the cache holds the prompt and every token of the run, whatever --steps asks for
+    need = args.prompt_len + budget + 64
+    max_len = max(args.max_len, (need + 255) // 256 * 256)
     if tp or batch > 1:
         from eventgpt_amd.parallel.tp import TensorParallelEngine
-        return TensorParallelEngine(model, dist.group.WORLD if tp else None, max_len=args.max_len,
+        return TensorParallelEngine(model, dist.group.WORLD if tp else None, max_len=max_len,
                                     max_batch=batch, max_new_tokens=budget, use_graph=not args.no_graph,
                                     allreduce=args.allreduce, **ekw)
-    return model.engine(max_len=args.max_len, max_new_tokens=budget, use_graph=not args.no_graph, **ekw)
+    return model.engine(max_len=max_len, max_new_tokens=budget, use_graph=not args.no_graph, **ekw)
 
 
 def timed_decode(args, engine, embeds, batch: int, dist, dev):
