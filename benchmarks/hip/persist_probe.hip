@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NW * 64, 1) void probe_kernel(Probe p) {
       if (m == 0 && p.barriers >= 2) {
         // attention stand-in: every wave reads its slice of this layer's K/V, the block leaves a
         // partial, barrier, every block merges eight partials, barrier
-        const int layer = cs.m == 1 ? cs.layer : cs.layer;   // still the layer of the qkv phase
+        const int layer = cs.layer;   // advance() moved to the o_proj phase of the same layer
         const size_t per_wave = p.kv_bytes / (NB * NW) / CH * CH;
         const unsigned char* kp = p.kv + static_cast<size_t>(layer) * p.kv_bytes + static_cast<size_t>(g) * per_wave;
         float a = 0.f;
