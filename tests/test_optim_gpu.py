@@ -202,3 +202,25 @@ def test_wgrad_written_straight_into_the_flat_gradient_buffer():
         results.append([p.detach().clone() for p in net.parameters()])
     for pd, pz in zip(*results):
         assert torch.equal(pd, pz)
+
+
+@pytest.mark.timeout(240)
+def test_direct_gradients_under_data_parallel_two_ranks(tmp_path):
+    """Two ranks on GPU 0 (gloo, host-copied reduce-scatter / all-gather): the sharded AdamW with the
+    wgrad GEMM writing into its flat buffer ends at the same parameters, bit for bit, as the
+    zero-and-accumulate path, and the ranks agree."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "dp_gpu.json")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29567", os.path.join(here, "_dp_gpu_worker.py"), out]
+    print("launching 2-rank DP worker", flush=True)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=220)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    got = json.load(open(out))
+    assert got["world"] == 2 and got["ranks_agree"] and got["equal"], got
+    assert got["norms_direct"] == got["norms_zero"]
