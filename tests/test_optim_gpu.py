@@ -224,3 +224,69 @@ def test_direct_gradients_under_data_parallel_two_ranks(tmp_path):
     got = json.load(open(out))
     assert got["world"] == 2 and got["ranks_agree"] and got["equal"], got
     assert got["norms_direct"] == got["norms_zero"]
+
+
+_RCCL_DP_ONE_RANK = r"""
+import os, sys, json
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", sys.argv[1])
+sys.path.insert(0, sys.argv[2])
+import torch, torch.distributed as dist
+from eventgpt_amd.models.llama import Linear, RMSNorm
+from eventgpt_amd.parallel.dp import ShardedAdamW
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+
+
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = Linear(256, 512, bias=False)
+        self.b = Linear(512, 256, bias=False)
+        self.norm = RMSNorm(256)
+
+    def forward(self, x):
+        return self.b(self.a(self.norm(x)))
+
+
+def run(direct):
+    torch.manual_seed(0)
+    net = Net().to(dev, torch.bfloat16)
+    opt = ShardedAdamW(net.parameters(), lr=1e-2, weight_decay=0.01, bucket_bytes=1 << 18, direct_grads=direct)
+    g = torch.Generator(device=dev).manual_seed(1)
+    hooked = bool(opt.overlap)
+    for _ in range(3):
+        x = torch.randn(64, 256, device=dev, generator=g).to(torch.bfloat16)
+        opt.zero_grad()
+        net(x).float().pow(2).mean().backward()
+        pending = [b.pending for b in opt.buckets]      # the post-accumulate hooks counted every gradient in
+        opt.step(max_grad_norm=1.0)
+    return torch.cat([p.detach().float().reshape(-1) for p in net.parameters()]).cpu(), hooked, pending
+
+
+plain, _, _ = run(False)                                   # no process group yet: no hooks
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+direct, hooked, pending = run(True)                        # RCCL group of one: hooks + direct gradients
+print(json.dumps({"equal": bool(torch.equal(plain, direct)), "hooked": hooked, "pending": pending}))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.timeout(240)
+def test_direct_gradients_with_the_rccl_overlap_hooks_single_rank():
+    """On an RCCL group the sharded AdamW counts gradients in from post-accumulate hooks (to start a
+    bucket's reduce-scatter during backward).  With direct gradient slots the hook also settles the
+    slot; a group of one rank (all a one-GPU box can form) runs exactly that code: same parameters as
+    the hook-free zero-and-accumulate path, every bucket counted down to zero."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    print("launching single-rank RCCL DP worker", flush=True)
+    r = subprocess.run([sys.executable, "-c", _RCCL_DP_ONE_RANK, "29569", root], env=env, capture_output=True,
+                       text=True, timeout=220)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2500:])
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["hooked"] and got["equal"] and all(p == 0 for p in got["pending"]), got
