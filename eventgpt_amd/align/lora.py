@@ -74,7 +74,8 @@ class LoRALinear(nn.Module):
             return self.base(x, act=act, residual=residual)
         if act:
             raise NotImplementedError("LoRA on a layer with a fused activation is not supported")
-        low = self.lora_B(self.lora_A(self.lora_dropout(x))) * self.scaling
+        # the scale rides on the rank-r intermediate ([rows, r]), not on the [rows, out] product
+        low = self.lora_B(self.lora_A(self.lora_dropout(x)) * self.scaling)
         extra = low if residual is None else low + residual
         # the low-rank update rides on the base GEMM's residual epilogue
         return self.base(x) + extra if plain else self.base(x, residual=extra)
