@@ -187,6 +187,30 @@ struct ARCallSet { ARCall c[COMM_MAX_RANKS]; };   // one per rank driven by this
 int comm_plan(int M, int N, int* chunk, int* bpr);   // blocks of a call, 0 if it does not fit
 void launch_oneshot_allreduce(const ARCallSet& calls, int n_virtual, int blocks, int nslab, int world,
                               hipStream_t st);
+// Two-shot all-reduce of prefill-sized bf16 messages: reduce-scatter + all-gather, both as direct
+// pushes into peer-mapped staging slots.  A block moves one PIECE (256 lanes x 16 bytes) of every
+// rank's slice; staging and flags are uncached device memory, double-buffered by call parity.
+constexpr int COMM2_PIECE = 2048;       // bf16 elements per block
+struct Comm2State {           // device memory, one per rank
+  bf16_t* stage1[COMM_MAX_RANKS];   // scatter slots  [2][world][slice_cap] of rank p (peer-mapped; [rank] is mine)
+  bf16_t* stage2[COMM_MAX_RANKS];   // gather slots, same shape
+  unsigned* flag[COMM_MAX_RANKS];   // [2 phases][2][world][pieces_cap]
+  unsigned* epoch;                  // [pieces_cap] calls completed per piece (local)
+  unsigned* err;                    // [4]: timeouts, then epoch / peer / piece of the last one (local)
+  long long slice_cap;              // elements per (parity, source rank) slot: pieces_cap * COMM2_PIECE
+  int pieces_cap;
+  int rank, world;
+  unsigned spin_limit;
+};
+struct TSCall {
+  const Comm2State* cs;
+  const bf16_t* x;            // [E] this rank's addend
+  bf16_t* out;                // [E] the sum (may be x)
+  long long E;                // elements, a multiple of 8
+  int pieces;                 // pieces per slice: slice s = elements [s, s + 1) * pieces * COMM2_PIECE
+};
+struct TSCallSet { TSCall c[COMM_MAX_RANKS]; };
+void launch_twoshot_allreduce(const TSCallSet& calls, int n_virtual, int pieces, int world, hipStream_t st);
 void launch_sum_slabs(const float* partial, int nslab, long long n, float* out, hipStream_t st);
 void launch_argmax_pair_local(const float* part_val, const int* part_idx, int B, int n_part,
                               int index_offset, unsigned* pair, hipStream_t st);

@@ -1,4 +1,4 @@
-// Peer-mapped communication buffers for the one-shot all-reduce (comm.hip).
+// Peer-mapped communication buffers for the one-shot and two-shot all-reduces (comm.hip).
 //
 // Each rank allocates its receive buffer and flag words as UNCACHED device memory
 // (hipExtMallocWithFlags + hipDeviceMallocUncached: remote posted writes and local polls
@@ -167,6 +167,71 @@ bool comm_allreduce(std::vector<Tensor> state, std::vector<Tensor> partial,
   return true;
 }
 
+// Device-resident Comm2State of one rank (two-shot all-reduce).  stage1 / stage2 / flag: W device
+// addresses each (this rank's own buffers at index `rank`); every stage buffer holds
+// 2 * world * pieces_cap * COMM2_PIECE bf16, every flag buffer 2 * 2 * world * pieces_cap words.
+Tensor comm2_make_state(std::vector<int64_t> stage1, std::vector<int64_t> stage2, std::vector<int64_t> flags,
+                        const Tensor& epoch, const Tensor& err, int64_t pieces_cap, int64_t rank, int64_t world,
+                        int64_t spin_limit) {
+  TORCH_CHECK(world >= 1 && world <= evgpt::COMM_MAX_RANKS && rank >= 0 && rank < world, "comm2_make_state: world size");
+  TORCH_CHECK((int64_t)stage1.size() == world && (int64_t)stage2.size() == world && (int64_t)flags.size() == world);
+  TORCH_CHECK(pieces_cap >= 1 && pieces_cap <= (1 << 20), "comm2_make_state: pieces_cap");
+  TORCH_CHECK(epoch.is_cuda() && epoch.scalar_type() == at::kInt && epoch.is_contiguous() && epoch.numel() >= pieces_cap,
+              "comm2_make_state: epoch int32 [pieces_cap]");
+  TORCH_CHECK(err.is_cuda() && err.scalar_type() == at::kInt && err.is_contiguous() && err.numel() >= 4);
+  TORCH_CHECK(spin_limit >= 1 && spin_limit < (1ll << 31));
+  evgpt::Comm2State s{};
+  for (int64_t p = 0; p < world; ++p) {
+    TORCH_CHECK(stage1[p] != 0 && stage2[p] != 0 && flags[p] != 0 && (stage1[p] & 15) == 0 && (stage2[p] & 15) == 0,
+                "comm2_make_state: null/unaligned peer buffer");
+    s.stage1[p] = reinterpret_cast<evgpt::bf16_t*>((uintptr_t)stage1[p]);
+    s.stage2[p] = reinterpret_cast<evgpt::bf16_t*>((uintptr_t)stage2[p]);
+    s.flag[p] = reinterpret_cast<unsigned*>((uintptr_t)flags[p]);
+  }
+  s.epoch = reinterpret_cast<unsigned*>(epoch.data_ptr<int>());
+  s.err = reinterpret_cast<unsigned*>(err.data_ptr<int>());
+  s.pieces_cap = (int)pieces_cap;
+  s.slice_cap = pieces_cap * evgpt::COMM2_PIECE;
+  s.rank = (int)rank; s.world = (int)world; s.spin_limit = (unsigned)spin_limit;
+  Tensor out = at::empty({(int64_t)sizeof(s)}, epoch.options().dtype(at::kByte));
+  EVGPT_HIP_CHECK(hipMemcpy(out.data_ptr(), &s, sizeof(s), hipMemcpyHostToDevice));
+  return out;
+}
+
+int64_t comm2_piece() { return evgpt::COMM2_PIECE; }
+
+// Two-shot all-reduce of equal-shaped bf16 tensors, one list entry per rank driven by THIS launch
+// (one in production).  out[v] may be x[v].  Returns false (and launches nothing) if the message
+// does not fit `pieces_cap` pieces per slice.
+bool comm2_allreduce(std::vector<Tensor> state, std::vector<Tensor> x, std::vector<Tensor> out, int64_t pieces_cap,
+                     int64_t world) {
+  TORCH_CHECK(world >= 2 && world <= evgpt::COMM_MAX_RANKS, "comm2_allreduce: 2..8 ranks");
+  const int64_t V = (int64_t)state.size();
+  TORCH_CHECK(V >= 1 && V <= evgpt::COMM_MAX_RANKS && (int64_t)x.size() == V && (int64_t)out.size() == V,
+              "comm2_allreduce: one entry per driven rank");
+  const int64_t E = x[0].numel();
+  TORCH_CHECK(E >= 8 && E % 8 == 0, "comm2_allreduce: a multiple of 8 elements");
+  const int64_t per_rank = (E + world - 1) / world;
+  const int64_t pieces = (per_rank + evgpt::COMM2_PIECE - 1) / evgpt::COMM2_PIECE;
+  if (pieces > pieces_cap) return false;
+  evgpt::TSCallSet calls{};
+  for (int64_t v = 0; v < V; ++v) {
+    TORCH_CHECK(state[v].is_cuda() && state[v].scalar_type() == at::kByte &&
+                state[v].numel() == (int64_t)sizeof(evgpt::Comm2State), "comm2_allreduce: bad state");
+    check_bf(x[v], E, "x");
+    check_bf(out[v], E, "out");
+    TORCH_CHECK((reinterpret_cast<uintptr_t>(x[v].data_ptr()) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(out[v].data_ptr()) & 15) == 0, "comm2_allreduce: 16-byte aligned tensors");
+    evgpt::TSCall& c = calls.c[v];
+    c.cs = reinterpret_cast<const evgpt::Comm2State*>(state[v].data_ptr());
+    c.x = reinterpret_cast<const evgpt::bf16_t*>(x[v].data_ptr());
+    c.out = reinterpret_cast<evgpt::bf16_t*>(out[v].data_ptr());
+    c.E = E; c.pieces = (int)pieces;
+  }
+  evgpt::launch_twoshot_allreduce(calls, (int)V, (int)pieces, (int)world, c10::hip::getCurrentHIPStream().stream());
+  return true;
+}
+
 Tensor sum_slabs(const Tensor& partial) {
   TORCH_CHECK(partial.is_cuda() && partial.scalar_type() == at::kFloat && partial.is_contiguous() &&
               partial.dim() == 3 && (partial.size(1) * partial.size(2)) % 4 == 0, "sum_slabs: fp32 [nslab, M, N]");
@@ -207,6 +272,9 @@ TORCH_LIBRARY_FRAGMENT(evgpt, m) {
   m.def("comm_flag_bytes() -> int", &comm_flag_bytes);
   m.def("comm_make_state(int[] data_ptrs, int[] flag_ptrs, Tensor epoch, Tensor err, int rank, int world, int spin_limit) -> Tensor", &comm_make_state);
   m.def("comm_allreduce(Tensor[] state, Tensor[] partial, Tensor?[] res, Tensor?[] x_out, Tensor? norm_w, Tensor?[] xn_out, Tensor?[] sum_out, float eps, int world) -> bool", &comm_allreduce);
+  m.def("comm2_make_state(int[] stage1, int[] stage2, int[] flags, Tensor epoch, Tensor err, int pieces_cap, int rank, int world, int spin_limit) -> Tensor", &comm2_make_state);
+  m.def("comm2_piece() -> int", &comm2_piece);
+  m.def("comm2_allreduce(Tensor[] state, Tensor[] x, Tensor(a!)[] out, int pieces_cap, int world) -> bool", &comm2_allreduce);
   m.def("sum_slabs(Tensor partial) -> Tensor", &sum_slabs);
   m.def("argmax_pair_local(Tensor part_val, Tensor part_idx, int B, int n_part, int index_offset, Tensor(a!) pair) -> ()", &argmax_pair_local);
   m.def("argmax_pair_select(Tensor pairs, int W, int B, Tensor(a!) token) -> ()", &argmax_pair_select);

@@ -26,6 +26,9 @@
 //    Every wait is bounded: on a timeout the kernel records it, finishes with whatever
 //    arrived and exits normally; the host reads err[0] and raises.
 //
+//    A two-shot variant (reduce-scatter + all-gather, both as direct pushes) carries the
+//    bandwidth-bound bf16 messages of a sharded prefill; it is described at its kernel below.
+//
 // 2. Helpers for the RCCL path and the vocab-parallel head: slab pre-sum, (max, index)
 //    pair kernels for the distributed argmax.
 #include "common.h"
@@ -218,6 +221,120 @@ void launch_oneshot_allreduce(const ARCallSet& calls, int n_virtual, int blocks,
   if (world <= 2) launch_ar_w<2>(calls, g, nslab, st);
   else if (world <= 4) launch_ar_w<4>(calls, g, nslab, st);
   else launch_ar_w<8>(calls, g, nslab, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// 1b. Two-shot all-reduce for bandwidth-bound messages (the [S, 4096] products of a sharded
+//     prefill: 5 MB at 636 tokens).  One-shot would make every rank receive W - 1 whole messages;
+//     here rank r owns slice r of the message:
+//       scatter: every rank pushes piece b of slice p into peer p's slot [parity][me], flag
+//       reduce : the owner sums its own piece and the W - 1 staged ones in rank order (fp32)
+//       gather : and pushes the bf16 result into every peer's second slot [parity][me], flag;
+//                each rank copies the W - 1 arrived pieces into its output.
+//     Every rank sends and receives (W - 1) / W of the message twice, spread over all links at
+//     once (a ring moves the same bytes through one link per hop).  The sum of an element is
+//     computed by exactly one rank, so the result is bit-identical everywhere.  Flags, parity,
+//     bounded waits and the error word work as in the one-shot kernel; a block depends only on
+//     the blocks of the SAME index on the other ranks, never on another block of its own grid.
+template <int WT>
+__global__ __launch_bounds__(256) void twoshot_allreduce_kernel(TSCallSet calls) {
+  const TSCall& c = calls.c[blockIdx.y];
+  const Comm2State* __restrict__ cs = c.cs;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int W = cs->world, me = cs->rank;
+  unsigned e = cs->epoch[b] + 1u;
+  if (e == 0u) e = 1u;
+  const unsigned parity = e & 1u;
+  const long long slice = static_cast<long long>(c.pieces) * COMM2_PIECE;
+  const long long in_slice = static_cast<long long>(b) * COMM2_PIECE + tid * 8;    // this lane's 8 elements
+  const long long my_slot = (static_cast<long long>(parity) * W + me) * cs->slice_cap + in_slice;
+  const long long flag_plane = static_cast<long long>(W) * cs->pieces_cap;          // words per (phase, parity)
+  auto flag_of = [&](int phase, int src) {
+    return (static_cast<long long>(phase) * 2 + parity) * flag_plane + static_cast<long long>(src) * cs->pieces_cap + b;
+  };
+  auto publish_and_wait = [&](int phase) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < 64) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid < W && tid != me)
+        __hip_atomic_store(cs->flag[tid] + flag_of(phase, me), e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (tid < W && tid != me) {
+        const unsigned* f = cs->flag[me] + flag_of(phase, tid);
+        unsigned spins = 0;
+        while (poll_u32(f) != e) {
+          if (++spins > cs->spin_limit) {        // give up: record it and go on with what arrived
+            atomicAdd(cs->err, 1u);
+            cs->err[1] = e; cs->err[2] = static_cast<unsigned>(tid); cs->err[3] = static_cast<unsigned>(b);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  };
+
+  // ---- scatter: piece b of slice p goes to rank p
+  u32x4_t mine = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int p = 0; p < WT; ++p) {
+    if (p >= W) continue;
+    const long long el = static_cast<long long>(p) * slice + in_slice;
+    const u32x4_t v = el < c.E ? load16(c.x + el) : u32x4_t{0u, 0u, 0u, 0u};
+    if (p == me) mine = v;
+    else *reinterpret_cast<u32x4_t*>(cs->stage1[p] + my_slot) = v;
+  }
+  publish_and_wait(0);
+
+  // ---- reduce my slice's piece in rank order, fp32
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  {
+    u32x4_t t[WT];
+#pragma unroll
+    for (int q = 0; q < WT; ++q) {
+      // slots of absent ranks (and my own, which stays in registers) are read and dropped
+      const int qq = q < W ? q : 0;
+      t[q] = *reinterpret_cast<const u32x4_t*>(cs->stage1[me] + (static_cast<long long>(parity) * W + qq) * cs->slice_cap + in_slice);
+    }
+#pragma unroll
+    for (int q = 0; q < WT; ++q) {
+      if (q >= W) continue;
+      const u32x4_t v = q == me ? mine : t[q];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc[2 * i] += bf16lo(v[i]); acc[2 * i + 1] += bf16hi(v[i]); }
+    }
+  }
+  const u32x4_t r = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
+                     pack_bf16x2(acc[6], acc[7])};
+  const long long my_el = static_cast<long long>(me) * slice + in_slice;
+  if (my_el < c.E) *reinterpret_cast<u32x4_t*>(c.out + my_el) = r;
+  // ---- gather: the reduced piece goes to every peer
+#pragma unroll
+  for (int p = 0; p < WT; ++p) {
+    if (p >= W || p == me) continue;
+    *reinterpret_cast<u32x4_t*>(cs->stage2[p] + my_slot) = r;
+  }
+  publish_and_wait(1);
+#pragma unroll
+  for (int q = 0; q < WT; ++q) {
+    if (q >= W || q == me) continue;
+    const long long el = static_cast<long long>(q) * slice + in_slice;
+    if (el < c.E)
+      *reinterpret_cast<u32x4_t*>(c.out + el) =
+          *reinterpret_cast<const u32x4_t*>(cs->stage2[me] + (static_cast<long long>(parity) * W + q) * cs->slice_cap + in_slice);
+  }
+  if (tid == 0) cs->epoch[b] = e;
+}
+
+void launch_twoshot_allreduce(const TSCallSet& calls, int n_virtual, int pieces, int world, hipStream_t st) {
+  const dim3 g(pieces, n_virtual), b(256);
+  if (world <= 2) hipLaunchKernelGGL(twoshot_allreduce_kernel<2>, g, b, 0, st, calls);
+  else if (world <= 4) hipLaunchKernelGGL(twoshot_allreduce_kernel<4>, g, b, 0, st, calls);
+  else hipLaunchKernelGGL(twoshot_allreduce_kernel<8>, g, b, 0, st, calls);
 }
 
 // ---------------------------------------------------------------- RCCL-path helpers

@@ -1,4 +1,5 @@
-"""One-shot all-reduce over peer-mapped buffers (the tensor-parallel decode collective).
+"""Push all-reduces over peer-mapped buffers: one-shot for the tensor-parallel decode step,
+two-shot for the prefill.
 
 A decode step of a tensor-parallel 7B decoder issues 64 all-reduces of ``[B, 4096]`` partial
 sums (16 KB at one stream, 512 KB at 32): latency-bound messages for which a ring over the
@@ -13,6 +14,10 @@ like any other kernel.  This module owns the buffers:
 * ``VirtualGroup`` -- W ranks inside ONE process on one GPU (all of them driven by a single
   launch, every block co-resident): how the kernel and its protocol are tested where only one
   GPU is at hand.
+* ``TwoShotAllReduce`` / ``VirtualTwoShot`` -- the same pair for the bandwidth-bound messages of a
+  sharded prefill (``[rows, hidden]`` bf16): rank r owns slice r, the other ranks push their pieces
+  of it into r's staging slots, r sums them in fp32 and pushes the result into every peer's second
+  slot (reduce-scatter + all-gather as direct writes over all links at once).
 
 RCCL stays the selectable default (``EVGPT_TP_ALLREDUCE=rccl|oneshot|auto``); ``auto`` runs
 ``self_test`` against ``dist.all_reduce`` once at start-up and keeps RCCL on any mismatch or
@@ -180,6 +185,100 @@ class VirtualGroup(_AllReduceBase):
         return bool(_raw().comm_allreduce([self._states[r] for r in ranks], [partials[r] for r in ranks],
                                           pick(res), pick(x_out), norm_w, pick(xn_out), pick(sum_out),
                                           float(eps), self.world))
+
+
+# ----------------------------------------------------------------------- two-shot (large messages)
+class _TwoShotBuffers:
+    """Scatter / gather staging, flags, epochs and error words of one rank for messages of up to
+    ``max_elems`` bf16 elements over ``world`` ranks."""
+
+    def __init__(self, device: torch.device, world: int, max_elems: int):
+        raw = _raw()
+        piece = int(raw.comm2_piece())
+        per_rank = -(-int(max_elems) // world)
+        self.pieces_cap = max(1, -(-per_rank // piece))
+        stage_bytes = 2 * world * self.pieces_cap * piece * 2
+        flag_bytes = -(-(2 * 2 * world * self.pieces_cap * 4) // 16) * 16
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.stage1 = raw.comm_alloc(stage_bytes, idx)
+        self.stage2 = raw.comm_alloc(stage_bytes, idx)
+        self.flag = raw.comm_alloc(flag_bytes, idx)
+        self.epoch = torch.zeros(self.pieces_cap, dtype=torch.int32, device=device)
+        self.err = torch.zeros(4, dtype=torch.int32, device=device)
+
+
+class TwoShotAllReduce(_AllReduceBase):
+    """Reduce-scatter + all-gather over peer-mapped staging buffers for the bandwidth-bound
+    all-reduces of a sharded prefill (``[S, hidden]`` bf16).  This process's rank of the group."""
+
+    def __init__(self, group, device: torch.device, max_elems: int, spin_limit: int = DEFAULT_SPIN_LIMIT):
+        raw = _raw()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if not 2 <= self.world <= 8:
+            raise ValueError("two-shot all-reduce: 2..8 ranks")
+        self.device = device
+        self.buf = _TwoShotBuffers(device, self.world, max_elems)
+        mine = tuple(raw.comm_ipc_handle(t).tolist() for t in (self.buf.stage1, self.buf.stage2, self.buf.flag))
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine, group=group)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        self._opened: List[int] = []
+        ptrs = ([], [], [])
+        for r, hs in enumerate(handles):
+            for k, (h, own) in enumerate(zip(hs, (self.buf.stage1, self.buf.stage2, self.buf.flag))):
+                if r == self.rank:
+                    ptrs[k].append(own.data_ptr())
+                else:
+                    p = int(raw.comm_ipc_open(torch.tensor(h, dtype=torch.uint8), idx))
+                    self._opened.append(p)
+                    ptrs[k].append(p)
+        self.state = raw.comm2_make_state(ptrs[0], ptrs[1], ptrs[2], self.buf.epoch, self.buf.err,
+                                          self.buf.pieces_cap, self.rank, self.world, int(spin_limit))
+        self._states = [self.state]
+        self._errs = [self.buf.err]
+        dist.barrier(group=group)       # nobody pushes before every rank has mapped and zeroed its buffers
+
+    def close(self) -> None:
+        raw = _raw()
+        for p in self._opened:
+            raw.comm_ipc_close(p)
+        self._opened = []
+
+    def reduce(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> bool:
+        """Sum ``x`` (contiguous bf16, a multiple of 8 elements) over the group into ``out`` (default:
+        in place); fp32 accumulation in rank order, the same bits on every rank.  Returns False without
+        launching if the message is larger than the buffers were sized for (take RCCL then)."""
+        out = x if out is None else out
+        return bool(_raw().comm2_allreduce([self.state], [x], [out], self.buf.pieces_cap, self.world))
+
+
+class VirtualTwoShot(_AllReduceBase):
+    """``world`` two-shot ranks in one process on one GPU; a single launch drives all of them.
+    Every block of every rank must be resident at once (a rank's block waits for the same block of
+    the other ranks), so messages here stay small: world * pieces blocks <= a few hundred."""
+
+    def __init__(self, world: int, device: torch.device, max_elems: int, spin_limit: int = DEFAULT_SPIN_LIMIT):
+        raw = _raw()
+        if not 2 <= world <= 8:
+            raise ValueError("virtual two-shot group: 2..8 ranks")
+        self.world, self.device = world, device
+        self.bufs = [_TwoShotBuffers(device, world, max_elems) for _ in range(world)]
+        s1 = [b.stage1.data_ptr() for b in self.bufs]
+        s2 = [b.stage2.data_ptr() for b in self.bufs]
+        fl = [b.flag.data_ptr() for b in self.bufs]
+        self.pieces_cap = self.bufs[0].pieces_cap
+        self._states = [raw.comm2_make_state(s1, s2, fl, b.epoch, b.err, b.pieces_cap, r, world, int(spin_limit))
+                        for r, b in enumerate(self.bufs)]
+        self._errs = [b.err for b in self.bufs]
+
+    def reduce(self, xs: Sequence[torch.Tensor], outs: Optional[Sequence[torch.Tensor]] = None,
+               ranks: Optional[Sequence[int]] = None) -> bool:
+        ranks = list(range(self.world)) if ranks is None else list(ranks)
+        outs = xs if outs is None else outs
+        return bool(_raw().comm2_allreduce([self._states[r] for r in ranks], [xs[r] for r in ranks],
+                                           [outs[r] for r in ranks], self.pieces_cap, self.world))
 
 
 def allreduce_mode() -> str:

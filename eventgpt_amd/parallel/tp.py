@@ -237,6 +237,7 @@ class TensorParallelEngine(GenerationEngine):
         super().__init__(model, max_len=max_len, max_batch=max_batch, **kw)
         dev = self.device
         self.oneshot = None
+        self.twoshot = None
         self.allreduce_kind = "none"
         if self.tp_world > 1:
             from . import comm
@@ -254,6 +255,10 @@ class TensorParallelEngine(GenerationEngine):
                 ar = comm.OneShotAllReduce(self.tp_group, dev)
                 if mode == "oneshot" or ar.self_test():
                     self.oneshot, self.allreduce_kind = ar, "oneshot"
+                    # the prefill's [rows, hidden] products are bandwidth-bound: two-shot pushes,
+                    # sized for a full cache of rows (larger packs take the library collective)
+                    rows = min(max(self.l_max, self.PACK_ROWS), 16384)
+                    self.twoshot = comm.TwoShotAllReduce(self.tp_group, dev, rows * self.H)
                 else:
                     ar.close()
 
@@ -290,6 +295,9 @@ class TensorParallelEngine(GenerationEngine):
 
     # -------------------------------------------------------------- collectives
     def _reduce(self, t: torch.Tensor) -> torch.Tensor:
+        if (self.twoshot is not None and t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() % 8 == 0
+                and self.twoshot.reduce(t)):
+            return t
         return _all_reduce(t, self.tp_group)
 
     def _allreduce_f32(self, t: torch.Tensor) -> torch.Tensor:

@@ -3,8 +3,9 @@ group is gloo (host tensors only), graphs are off (a host copy cannot be capture
 
 Two ranks run the sharded engine in four configurations -- 2 and 6 streams (the weight-streaming
 GEMV path and the split-K GEMM + fused-consumer path), each with the library all-reduce
-(gloo through host copies) and with the one-shot push all-reduce over IPC-mapped buffers
-(two processes, one GPU: real ``hipIpcMemHandle`` exchange, every device wait bounded) --
+(gloo through host copies) and with the push all-reduces over IPC-mapped buffers (one-shot for the
+decode steps, two-shot for the prefill's [rows, hidden] products; two processes, one GPU: real
+``hipIpcMemHandle`` exchange, every device wait bounded) --
 and compare each against the unsharded engine on the same prompts; eight ranks (one attention
 head, 192 padded MLP columns and 65 vocabulary rows each) run the library all-reduce only."""
 import json
@@ -47,6 +48,10 @@ def run_config(model_fn, info, prompts, want_x, allreduce):
     packed = []
     inner = eng._forward_rows_packed
     eng._forward_rows_packed = lambda e, s: (packed.append(len(s)), inner(e, s))[1]
+    big = []
+    if eng.twoshot is not None:
+        inner2 = eng.twoshot.reduce
+        eng.twoshot.reduce = lambda x, out=None: (lambda ok: (big.append(bool(ok)), ok)[1])(inner2(x, out))
     eng.prefill_batch(prompts)
     first_tok = [int(eng.out_tokens[b, 0]) for b in range(B)]
     c0 = [float(cos(eng.x[b].float(), want_x[b][0], dim=0)) for b in range(B)]
@@ -63,6 +68,8 @@ def run_config(model_fn, info, prompts, want_x, allreduce):
     timeouts = 0
     if eng.oneshot is not None:
         timeouts = int(eng.oneshot.buf.err[0].item())
+    if eng.twoshot is not None:
+        timeouts += int(eng.twoshot.buf.err[0].item())
     rows = [None] * info.world
     dist.all_gather_object(rows, row.tolist())
     gathered = [None] * info.world
@@ -71,8 +78,11 @@ def run_config(model_fn, info, prompts, want_x, allreduce):
            "cos_prefill": c0, "cos_step": c1, "heads_local": eng.Hq, "i_local": eng.I,
            "logits_width": int(eng.logits.shape[1]), "logits_equal": all(r == rows[0] for r in rows),
            "allreduce_kind": eng.allreduce_kind, "packed_prompts": sum(packed)}
+    res["twoshot_calls"] = sum(big)
     if eng.oneshot is not None:
         eng.oneshot.close()
+    if eng.twoshot is not None:
+        eng.twoshot.close()
     return res
 
 

@@ -222,3 +222,77 @@ def test_rccl_collectives_record_into_a_graph_single_rank():
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2500:])
     got = json.loads(r.stdout.strip().splitlines()[-1])
     assert got["backend"] == "nccl" and got["ok"] == [True] * 4, got
+
+
+def _bf16_sum_oracle(xs):
+    total = torch.zeros_like(xs[0], dtype=torch.float32)
+    for x in xs:                            # rank order, fp32: the kernel's order
+        total = total + x.float()
+    return total.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("elems", [8, 4096, 636 * 64, 100_000, 3 * 2048 * 8])
+def test_twoshot_allreduce_matches_sum(dev, world, elems):
+    """Reduce-scatter + all-gather by direct pushes: every rank ends with the bf16 rounding of the fp32
+    sum in rank order, bit for bit, for sizes that do and do not fill the last piece; five calls in a
+    row flip the buffer parity; out of place and in place."""
+    from eventgpt_amd.parallel.comm import VirtualTwoShot
+    vg = VirtualTwoShot(world, dev, max_elems=120_000)
+    g = torch.Generator(device=dev).manual_seed(11 * world + elems)
+    for it in range(5):
+        xs = [torch.randn(elems, device=dev, generator=g).to(torch.bfloat16) for _ in range(world)]
+        want = _bf16_sum_oracle(xs)
+        if it % 2 == 0:
+            outs = [torch.empty_like(x) for x in xs]
+            assert vg.reduce(xs, outs)
+        else:
+            outs = [x.clone() for x in xs]
+            assert vg.reduce(outs)          # in place
+        torch.cuda.synchronize()
+        vg.check()
+        for r in range(world):
+            assert torch.equal(outs[r], want), (it, r, (outs[r].float() - want.float()).abs().max().item())
+
+
+def test_twoshot_allreduce_graph_replays_and_refusal(dev):
+    """A captured two-shot call replayed with new inputs (eager work and synchronisation in between)
+    matches the oracle every time; a message beyond the buffers is refused without a launch."""
+    from eventgpt_amd.parallel.comm import VirtualTwoShot
+    world, elems = 4, 50_000
+    vg = VirtualTwoShot(world, dev, max_elems=elems)
+    g = torch.Generator(device=dev).manual_seed(3)
+    xs = [torch.zeros(elems, dtype=torch.bfloat16, device=dev) for _ in range(world)]
+    outs = [torch.empty_like(x) for x in xs]
+    assert vg.reduce(xs, outs)              # warm-up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        assert vg.reduce(xs, outs)
+    for rep in range(4):
+        fresh = [torch.randn(elems, device=dev, generator=g).to(torch.bfloat16) for _ in range(world)]
+        for x, f in zip(xs, fresh):
+            x.copy_(f)
+        graph.replay()
+        torch.cuda.synchronize()
+        vg.check()
+        want = _bf16_sum_oracle(fresh)
+        for r in range(world):
+            assert torch.equal(outs[r], want), (rep, r)
+        _ = torch.randn(256, device=dev).sum().item()
+    too_big = [torch.zeros(elems * 3, dtype=torch.bfloat16, device=dev) for _ in range(world)]
+    assert vg.reduce(too_big) is False
+
+
+def test_twoshot_allreduce_wait_gives_up(dev):
+    """Only rank 0 of two is driven: its waits for the peer's scatter and gather flags give up after a
+    tiny spin limit, the kernel exits normally and the host sees the error."""
+    from eventgpt_amd.parallel.comm import VirtualTwoShot
+    vg = VirtualTwoShot(2, dev, max_elems=8192, spin_limit=64)
+    xs = [torch.ones(4096, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+    assert vg.reduce(xs, ranks=[0])
+    torch.cuda.synchronize()                  # the launch has drained
+    with pytest.raises(RuntimeError, match="timed out"):
+        vg.check()
+    vg.clear_errors()
+    vg.check()

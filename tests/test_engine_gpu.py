@@ -262,6 +262,9 @@ def test_tensor_parallel_engine_two_ranks(tmp_path):
         assert got["heads_local"] == 2 and got["i_local"] == 704 and got["logits_width"] == 515, key
         assert got["allreduce_kind"] == ("oneshot" if key.endswith("oneshot") else "gloo"), key
         assert got["timeouts"] == [0, 0], (key, got["timeouts"])
+        # the prefill products of more than 64 rows go through the two-shot kernel in that mode: two per
+        # layer for the pack of six prompts (the 2-stream prefills are short enough for the one-shot path)
+        assert got["twoshot_calls"] == (4 if key == "b6_oneshot" else 0), (key, got["twoshot_calls"])
         assert got["packed_prompts"] == (6 if key.startswith("b6") else 0), (key, got["packed_prompts"])
         assert got["ranks"][0] == got["ranks"][1], key          # the ranks agree token for token
         assert got["logits_equal"], key
