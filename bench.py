@@ -38,6 +38,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -67,6 +68,10 @@ def parse_args(argv=None):
                     help="multi-GPU tp runs: skip the additional 32-stream measurement")
     ap.add_argument("--no-dp-extra", action="store_true",
                     help="multi-GPU tp runs: skip the additional independent-replicas measurement")
+    ap.add_argument("--extras-timeout", type=float, default=300.0,
+                    help="multi-GPU tp runs: seconds the additional measurements may take after the headline one; "
+                         "past it the line is printed without them and the process ends (0 = no limit)")
+    ap.add_argument("--extras-stall", type=float, default=0.0, help=argparse.SUPPRESS)  # tests of the limit: idle first
     ap.add_argument("--nsplit", type=int, default=None, help="KV splits of the decode attention")
     ap.add_argument("--allreduce", choices=["rccl", "oneshot", "auto"], default=None,
                     help="tensor-parallel collective (default: EVGPT_TP_ALLREDUCE or rccl)")
@@ -277,40 +282,13 @@ def main(argv=None):
     graph_fallback = engine.graph_fallback
     tp_allreduce = getattr(engine, "allreduce_kind", "none")
 
-    # ---- the batched TP configuration (32 event streams), same group, same run.  Extras never
-    # cost the headline line: a failure is reported under the key instead of raised (every rank
-    # takes the same branch, so the group stays in step).
     extra = {}
-    if tp and args.batch == 1 and not args.no_batch32:
-        engine = model = None
-        torch.cuda.empty_cache()
-        try:
-            _, model32, _ = build_model(args, dev)
-            eng32 = build_engine(args, model32, dist, True, 32)
-            dt32 = timed_decode(args, eng32, embeds, 32, dist, dev)
-            extra["tp_batch32"] = {"tokens_per_s": round(32 * args.steps / dt32, 2),
-                                   "ms_per_step": round(dt32 * 1e3 / args.steps, 4), "global_batch": 32,
-                                   "graph_captured": bool(eng32.graph_captured),
-                                   "tp_allreduce": getattr(eng32, "allreduce_kind", "none")}
-        except Exception as e:
-            extra["tp_batch32"] = {"error": str(e)[:200]}
-        eng32 = model32 = None
-    # ---- independent replicas on the same GPUs (no communication in the step): the fabric-free
-    # bound the tensor-parallel numbers can be read against.  An extra key, never the value.
-    if tp and args.batch == 1 and not args.no_dp_extra:
-        engine = model = None
-        torch.cuda.empty_cache()
-        try:
-            _, model_dp, _ = build_model(args, dev)
-            eng_dp = build_engine(args, model_dp, None, False, 1)
-            dt_dp = timed_decode(args, eng_dp, embeds, 1, dist, dev)
-            extra["dp_replicas"] = {"tokens_per_s": round(world * args.steps / dt_dp, 2),
-                                    "ms_per_step": round(dt_dp * 1e3 / args.steps, 4), "global_batch": world,
-                                    "scaling": "weak", "graph_captured": bool(eng_dp.graph_captured)}
-        except Exception as e:
-            extra["dp_replicas"] = {"error": str(e)[:200]}
-        eng_dp = model_dp = None
-    if rank == 0:
+    printed = threading.Lock()
+
+    def emit() -> None:
+        """Rank 0's one JSON line; whichever of the normal end and the extras' time limit comes first."""
+        if rank != 0 or not printed.acquire(blocking=False):
+            return
         print(json.dumps({
             "metric": "decode tokens/sec (EventGPT-7B bf16 greedy, bs 1 per stream)" if args.batch == 1
             else f"decode tokens/sec (EventGPT-7B bf16 greedy, {args.batch} streams per engine)",
@@ -328,11 +306,66 @@ def main(argv=None):
             "rccl_world_size": rccl_world, **({"rehearsal_backend": "gloo"} if args.rehearsal else {}),
             "graph_captured": graph_captured,
             "graph_fallback": graph_fallback, "tp_allreduce": tp_allreduce,
-            **extra,
+            **dict(extra),
             "config": {"model": model_name, "global_batch": streams, "seq_len": S,
                        "event_frames": args.frames,
                        "parallelism": f"{args.parallelism}{world}"},
         }), flush=True)
+
+    # ---- extras (never the value).  They run after the headline measurement and must not be able
+    # to cost it: an exception is reported under the extra's key (every rank takes the same
+    # branch, so the group stays in step), and if the extras as a whole outlast their time limit
+    # -- ranks waiting in a collective that one of them has left -- every rank prints what it
+    # has and ends the process.
+    want_extras = tp and args.batch == 1 and not (args.no_batch32 and args.no_dp_extra)
+    if want_extras and args.extras_timeout > 0:
+        def give_up():
+            for name in ("tp_batch32", "dp_replicas"):
+                extra.setdefault(name, {"error": f"not finished within {args.extras_timeout} s"})
+            emit()
+            sys.stdout.flush()
+            os._exit(0)
+        watchdog = threading.Timer(args.extras_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+    else:
+        watchdog = None
+    if args.extras_stall > 0:
+        torch.cuda.synchronize()
+        time.sleep(args.extras_stall)
+    # the batched TP configuration (32 event streams), same group, same run
+    if tp and args.batch == 1 and not args.no_batch32:
+        engine = model = None
+        torch.cuda.empty_cache()
+        try:
+            _, model32, _ = build_model(args, dev)
+            eng32 = build_engine(args, model32, dist, True, 32)
+            dt32 = timed_decode(args, eng32, embeds, 32, dist, dev)
+            extra["tp_batch32"] = {"tokens_per_s": round(32 * args.steps / dt32, 2),
+                                   "ms_per_step": round(dt32 * 1e3 / args.steps, 4), "global_batch": 32,
+                                   "graph_captured": bool(eng32.graph_captured),
+                                   "tp_allreduce": getattr(eng32, "allreduce_kind", "none")}
+        except Exception as e:
+            extra["tp_batch32"] = {"error": str(e)[:200]}
+        eng32 = model32 = None
+    # independent replicas on the same GPUs (no communication in the step): the fabric-free
+    # bound the tensor-parallel numbers can be read against
+    if tp and args.batch == 1 and not args.no_dp_extra:
+        engine = model = None
+        torch.cuda.empty_cache()
+        try:
+            _, model_dp, _ = build_model(args, dev)
+            eng_dp = build_engine(args, model_dp, None, False, 1)
+            dt_dp = timed_decode(args, eng_dp, embeds, 1, dist, dev)
+            extra["dp_replicas"] = {"tokens_per_s": round(world * args.steps / dt_dp, 2),
+                                    "ms_per_step": round(dt_dp * 1e3 / args.steps, 4), "global_batch": world,
+                                    "scaling": "weak", "graph_captured": bool(eng_dp.graph_captured)}
+        except Exception as e:
+            extra["dp_replicas"] = {"error": str(e)[:200]}
+        eng_dp = model_dp = None
+    if watchdog is not None:
+        watchdog.cancel()
+    emit()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,5 +1,5 @@
 """Time the speculative-decoding verify pass (G draft rows in one forward) against a
-plain decode step on the 7B decoder.  ``python benchmarks/bench_verify.py [G] [prompt_len]``"""
+plain decode step on the 7B decoder.  ``python benchmarks/bench_verify.py [G] [prompt_len] [layers] [verify_only]``"""
 import sys
 import time
 
@@ -39,6 +39,10 @@ def ver():
     eng.pos.fill_(L); eng.step.fill_(1)
     eng.verify(draft, G)
 t_ver = timeit(ver)
+if len(sys.argv) > 4 and sys.argv[4] == "verify_only":      # for a kernel trace of the verify pass alone
+    timeit(ver, 200)
+    print(f"layers={cfg.num_hidden_layers} kv_len={L} decode_step={t_dec:.3f} ms  verify(G={G})={t_ver:.3f} ms", flush=True)
+    sys.exit(0)
 # same pass with the few-row fusion switched off (separate reduce / norm / rope / swiglu launches)
 eng.fused_rows = 0
 eng._verify_graphs.clear()

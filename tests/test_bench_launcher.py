@@ -74,3 +74,22 @@ def test_multi_rank_flow_rehearsal_on_one_gpu(n):
     assert got["value"] > 0 and got["config"]["parallelism"] == f"tp{n}" and got["tp_allreduce"] == "gloo"
     assert "error" not in got["tp_batch32"] and got["tp_batch32"]["tokens_per_s"] > 0, got["tp_batch32"]
     assert "error" not in got["dp_replicas"] and got["dp_replicas"]["global_batch"] == n, got["dp_replicas"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_extras_time_limit_keeps_the_headline_line():
+    """Additional measurements that outlast their limit (here: ranks idling on the host) do not cost the
+    headline line: rank 0 prints it with the extras marked unfinished and every rank ends with status 0."""
+    env = _clean_env()
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    print("launching the 2-rank rehearsal with a 2 s limit on the extras", flush=True)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--model", "small", "--rehearsal", "--steps", "4",
+                        "--warmup", "2", "--max-len", "1024", "--extras-timeout", "2", "--extras-stall", "30"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    got = json.loads(lines[0])
+    assert got["n_gpus"] == 2 and got["value"] > 0
+    assert "not finished" in got["tp_batch32"]["error"] and "not finished" in got["dp_replicas"]["error"]
