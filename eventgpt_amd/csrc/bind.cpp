@@ -111,7 +111,6 @@ Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bia
     evgpt::launch_gemv(bptr(w), bptr(x), bptr_mut(y), bptr_opt(bias), bptr_opt(res), nullptr, 0.f,
                        (int)act, (int)M, (int)N, (int)K, st);
   } else {
-    TORCH_CHECK(K % 64 == 0, "linear: the MFMA GEMM needs K % 64 == 0 (pad the operands)");
     const int sk = evgpt::gemm_splitk((int)M, (int)N, (int)K);
     Tensor ws;
     if (sk > 1) ws = at::empty({sk * M * N}, x.options().dtype(at::kFloat));
@@ -143,9 +142,9 @@ Tensor linear_swiglu(const Tensor& x, const Tensor& w) {
 //   a_t = false: a is [M,K]      a_t = true: a is [Kr,M] (the contraction runs over a's rows)
 //   w_t = false: w is [N,K]      w_t = true: w is [Kr,N]
 // These are the layouts of a linear layer's backward: dX = dY · W is (a = dY, w = W, w_t) and
-// dW = dY^T · X is (a = dY, w = X, both transposed).  A K-contiguous operand must have K % 64 == 0
-// (zero-padded by the caller); K-strided operands may have any number of rows Kr <= K as long as
-// the other operand is zero for k >= Kr.
+// dW = dY^T · X is (a = dY, w = X, both transposed).  K is the contraction rounded up to 64; an
+// operand may end up to 63 before it (K-strided: any number of rows Kr <= K; K-contiguous: a
+// multiple of 8 columns): the staging loads return zeros past an operand's real end.
 // `out`: write the product into this tensor (same dtype and element count as the result) instead of a
 // new one; it may be `res` itself, which makes the call an accumulation (each element is read and
 // written by the same lane).
@@ -160,19 +159,20 @@ Tensor linear_t(const Tensor& a, const Tensor& w, bool a_t, bool w_t, const c10:
   if (a_t) {
     TORCH_CHECK(M % 8 == 0 && M >= 8, "linear_t: K-strided A needs M % 8 == 0");
     ka_rows = a.size(0);
-  } else TORCH_CHECK(a.size(1) == K, "linear_t: K-contiguous A must be padded to K");
+  } else TORCH_CHECK(a.size(1) % 8 == 0 && a.size(1) >= 8, "linear_t: K-contiguous A needs a multiple of 8 columns");
   if (w_t) {
     TORCH_CHECK(N % 8 == 0 && N >= 8, "linear_t: K-strided W needs N % 8 == 0");
     kw_rows = w.size(0);
-  } else TORCH_CHECK(w.size(1) == K, "linear_t: K-contiguous W must be padded to K");
-  TORCH_CHECK(ka_rows >= 1 && kw_rows >= 1 && ka_rows <= K && kw_rows <= K && K - std::min(ka_rows, kw_rows) < 64,
+  } else TORCH_CHECK(w.size(1) % 8 == 0 && w.size(1) >= 8, "linear_t: K-contiguous W needs a multiple of 8 columns");
+  // the contraction lengths the two operands really have (a K-contiguous one: its columns)
+  const int64_t ka = a_t ? ka_rows : a.size(1), kw = w_t ? kw_rows : w.size(1);
+  TORCH_CHECK(ka >= 1 && kw >= 1 && ka <= K && kw <= K && K - std::min(ka, kw) < 64,
               "linear_t: K is the contraction rounded up to 64");
   TORCH_CHECK(a.numel() < (1ll << 30) && w.numel() < (1ll << 30), "linear_t: operands < 2 GiB each");
-  // K-strided operands end at their last row: the staging loads are range-checked against the rows that
-  // exist and return zeros past them.  A K-contiguous operand runs on into its next row instead, so it
-  // must carry the zero padding itself (0 x garbage is only 0 for finite garbage).
-  TORCH_CHECK((a_t && w_t) || ka_rows == K || kw_rows == K, "linear_t: with a K-contiguous operand, one operand must "
-              "cover the padded contraction (zero rows / columns for k past the real length)");
+  // Both kinds of operand end where their data ends: K-strided ones at their last row (the staging
+  // loads are range-checked against the rows that exist), K-contiguous ones at their last column
+  // (the last K-tile's chunks past it are given out-of-range offsets).  Either way the kernel sees
+  // zeros there, so no operand needs padding.
   if (bias.has_value()) { check_bf16(*bias, "bias"); TORCH_CHECK(bias->numel() == N); }
   if (res.has_value()) { check_bf16(*res, "residual"); TORCH_CHECK(res->numel() == M * N); }
   Tensor y;

@@ -75,6 +75,10 @@ struct GemmParams {
   // up region, so a lane holds both factors of its output columns and the intermediate [M, 2I]
   // tensor is never written.
   int glu_half;
+  // K-contiguous operands only: the columns a row really has when that is not a multiple of 64
+  // (0: K itself).  K is then the contraction rounded up to 64, and the last K-tile's chunks past
+  // k_cols -- which in memory are the start of the next row -- are staged as zeros.
+  int k_cols;
 };
 
 // wait until at most `n` of this wave's direct-to-LDS loads are still in flight
@@ -331,6 +335,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int lim_a = static_cast<int>(left_a > 0 ? left_a : 0), lim_w = static_cast<int>(left_w > 0 ? left_w : 0);
     const unsigned char* src_a = reinterpret_cast<const unsigned char*>(p.A) + adv_a;
     const unsigned char* src_w = reinterpret_cast<const unsigned char*>(p.W) + adv_w;
+    if (p.k_cols > 0 && k0 + BK > p.k_cols) {
+      // the one K-tile that runs past the end of a K-contiguous operand's rows (block-uniform
+      // branch): chunks at or past k_cols get an offset outside the descriptor's range
+      constexpr int kOut = 0x7ffffff0;
+#pragma unroll
+      for (int i = 0; i < BM / 32; ++i) {
+        const int rg = wid_u * (BM / 32) + i;
+        int vo = voff_a[i];
+        if constexpr (!AT) {
+          const int row = rg * 8 + srow;
+          if (k0 + (schunk ^ ((row >> 1) & 7)) * 8 >= p.k_cols) vo = kOut;
+        }
+        buffer_to_lds16(src_a, lim_a, base + rg * 1024, vo);
+      }
+#pragma unroll
+      for (int i = 0; i < BN / 32; ++i) {
+        const int rg = wid_u * (BN / 32) + i;
+        int vo = voff_w[i];
+        if constexpr (!BT) {
+          const int row = rg * 8 + srow;
+          if (k0 + (schunk ^ ((row >> 1) & 7)) * 8 >= p.k_cols) vo = kOut;
+        }
+        buffer_to_lds16(src_w, lim_w, base + A_BYTES + rg * 1024, vo);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < BM / 32; ++i) {  // BM/8 row-groups over 4 waves
       const int rg = wid_u * (BM / 32) + i;
@@ -765,8 +795,13 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
                       const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
                       float* amax_val, int* amax_idx, float* splitk_ws, int splitk,
                       hipStream_t st) {
+  // a contraction that is not a multiple of 64 (a multiple of 8: 16-byte chunks) runs to the next
+  // one, its last K-tile staged with zeros past the rows' real end (GemmParams::k_cols)
+  const int k_true = K;
+  K = (K + 63) / 64 * 64;
   GemmParams p{A, W, C, bias, res, Cf, M, N, K, lda, ldw, ldc, act, amax_val, amax_idx, 1, K,
                nullptr, 0, K, K};
+  p.k_cols = k_true == K ? 0 : k_true;
   if (splitk > 1 && splitk_ws && !amax_val) {
     const int ksteps = K / 64;
     p.splitk = splitk;
@@ -774,7 +809,8 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
     p.splitk = (K + p.k_per_split - 1) / p.k_per_split;  // drop empty trailing splits
     p.partial = splitk_ws;
   }
-  const GemmCfg cfg = pick_cfg(M, N, (splitk_ws && !amax_val) ? K : 0);
+  GemmCfg cfg = pick_cfg(M, N, (splitk_ws && !amax_val) ? K : 0);
+  if (cfg == CFG_256x256 && p.k_cols) cfg = CFG_128x128;   // the 8-wave kernel stages whole K-tiles only
   // One workgroup per CU means whole rounds of 256 tiles: a grid of 304 tiles takes as long as
   // one of 512.  When the last round would be under half full (and there are few rounds for it
   // to hide in), the 8-wave kernel takes the columns that make whole rounds and the 4-wave
@@ -848,13 +884,14 @@ void launch_gemm_glu(const bf16_t* A, const bf16_t* W, bf16_t* H, int M, int I, 
 // C[M,N] = opA · opW^T with K-strided operands: a_t -> A is stored [K][M] (lda = its row
 // stride), w_t -> W is stored [K][N].  Used by the backward products of a linear layer.
 // M (if a_t) and N (if w_t) must be multiples of 8 and >= 8; K a multiple of 64; ka_rows /
-// kw_rows <= K are the k-rows the K-strided operands really have (see GemmParams).
+// kw_rows <= K are the k-rows the K-strided operands really have (see GemmParams); a K-contiguous
+// operand has lda / ldw <= K columns (a multiple of 8), staged as zeros past them.
 template <bool AT, bool BT>
 static void launch_t(const GemmParams& p, hipStream_t st) {
   auto tiles = [&](int bm, int bn) {
     return static_cast<long long>((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
   };
-  const bool cols_ok = (!AT || p.M % 8 == 0) && (!BT || p.N % 8 == 0);
+  const bool cols_ok = (!AT || p.M % 8 == 0) && (!BT || p.N % 8 == 0) && p.k_cols == 0;
   if (p.splitk > 1) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
   else if ((g_forced_cfg == CFG_256x256 || (g_forced_cfg < 0 && use_256(p.M, p.N))) && cols_ok) launch_256<AT, BT>(p, st);
   else if (tiles(128, 128) >= 384) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
@@ -867,6 +904,9 @@ void launch_gemm_bf16_t(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, 
                         bool a_t, bool w_t, int ka_rows, int kw_rows, hipStream_t st, float* splitk_ws, int splitk) {
   GemmParams p{A, W, C, bias, res, Cf, M, N, K, lda, ldw, ldc, act, nullptr, nullptr, 1, K, nullptr, 0,
                ka_rows, kw_rows};
+  // the K-contiguous operand (at most one here) may end before the padded contraction does
+  const int cols = !a_t ? lda : (!w_t ? ldw : K);
+  p.k_cols = cols < K ? cols : 0;
   if (splitk > 1 && splitk_ws) {
     const int ksteps = K / 64;
     p.k_per_split = ((ksteps + splitk - 1) / splitk) * 64;

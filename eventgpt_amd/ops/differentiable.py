@@ -125,7 +125,9 @@ def linear_dgrad(gy: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """``dX [M,K] = dY [M,N] @ W [N,K]``: the contraction runs over W's ROWS, so W is the
     K-strided operand of the GEMM (read through transposing LDS loads, never copied)."""
     n = gy.shape[1]
-    return _raw().linear_t(_pad_cols(gy, _round64(n)), weight, False, True, None, None, 0, False, _round64(n))
+    if n % 8:                 # 16-byte chunks; otherwise the kernel itself stops at dY's last column
+        gy = _pad_cols(gy, _round64(n))
+    return _raw().linear_t(gy, weight, False, True, None, None, 0, False, _round64(n))
 
 
 def linear_wgrad(gy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -53,8 +53,7 @@ def _pad_k(x: torch.Tensor, w: torch.Tensor, mult: int = 64):
 
 def linear(x, weight, bias=None, act=None, residual=None, out_f32: bool = False):
     x, weight = _c(x), _c(weight)
-    rows = x.numel() // x.shape[-1]
-    if x.shape[-1] % 64 and (rows > 4 or x.shape[-1] % 8):
+    if x.shape[-1] % 8:       # the kernels move 16-byte chunks; any multiple of 8 runs as it is
         x, weight = _pad_k(x, weight)
     return _ops.linear(x, weight, None if bias is None else _c(bias),
                        None if residual is None else _c(residual), ACT_CODES[act], out_f32)

@@ -37,6 +37,29 @@ def test_dgrad_and_wgrad_match_fp32(dev, M, N, K):
     _close(dw, gy.float().t() @ x.float(), 2e-2 * math.sqrt(M / 16), 2e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(811, 4096, 16), (6, 4096, 16), (33, 64, 24), (130, 512, 72), (640, 1024, 200),
+                                   (811, 16, 4104), (6, 4096, 4104), (1030, 4096, 136)])
+def test_contraction_that_is_not_a_multiple_of_64(dev, M, N, K):
+    """K-contiguous operands whose rows end inside the last K-tile (low-rank products: K = 16): the
+    kernel stages zeros past the rows' end, so the result equals the zero-padded product bit for bit
+    and no operand is copied.  Every element is non-zero, so a chunk taken from the next row shows."""
+    from eventgpt_amd.ops import hip
+    x = _rand(M, K, dev=dev) + 0.25
+    w = _rand(N, K, dev=dev, seed=1, scale=0.1) + 0.125
+    res = _rand(M, N, dev=dev, seed=2)
+    y = hip.raw.linear(x, w, None, res, 0, False)
+    _close(y, x.float() @ w.float().t() + res.float(), 3e-2 * math.sqrt(K / 64 + 1), 2e-2)
+    if K < 2048:      # same tile configuration and split either way
+        pad = (-K) % 64
+        yp = hip.raw.linear(torch.nn.functional.pad(x, (0, pad)), torch.nn.functional.pad(w, (0, pad)), None, res, 0, False)
+        assert torch.equal(y, yp)
+    # dX = dY W with dY's columns ending inside the K-tile (contraction over N here)
+    if N % 8 == 0 and N % 64:
+        from eventgpt_amd.ops import differentiable as diff
+        gy = _rand(M, N, dev=dev, seed=3) + 0.25
+        _close(diff.linear_dgrad(gy, w), gy.float() @ w.float(), 3e-2 * math.sqrt(N / 64 + 1), 2e-2)
+
+
 def test_kstrided_operand_asymmetric_identity(dev):
     """A = I with an asymmetric other operand: a swapped row/column map or a wrong k order inside
     the transposed fragments shows up as exact mismatches."""
