@@ -19,7 +19,10 @@ A *step* is one decode step (one new token per stream).
   scaling, every decode step crosses 64 all-reduces -- and ``value`` is its tokens/s.  The
   batched configuration (32 event streams on the same TP group) is measured in the same run
   and reported under ``tp_batch32``, and so are N independent replicas (``dp_replicas``: no
-  communication in the step, the fabric-free bound).  ``--parallelism dp`` (independent replicas, no
+  communication in the step, the fabric-free bound) and, up to 4 ranks, the same tensor-parallel
+  measurement on the in-tree one-shot / two-shot all-reduce (``tp_oneshot``: run as a child job of
+  every rank on its own process group, because that collective has never crossed a real link).
+  The extras share a time limit (``--extras-timeout``) after which the line is printed without them.  ``--parallelism dp`` (independent replicas, no
   communication in the step) is available but is never the default: its curve says nothing
   about the fabric.
 
@@ -68,7 +71,11 @@ def parse_args(argv=None):
                     help="multi-GPU tp runs: skip the additional 32-stream measurement")
     ap.add_argument("--no-dp-extra", action="store_true",
                     help="multi-GPU tp runs: skip the additional independent-replicas measurement")
-    ap.add_argument("--extras-timeout", type=float, default=300.0,
+    ap.add_argument("--no-oneshot-extra", action="store_true",
+                    help="multi-GPU tp runs over RCCL: skip the additional run on the in-tree one-shot / two-shot "
+                         "all-reduce (a child job per rank, so that nothing it does can cost the headline line)")
+    ap.add_argument("--oneshot-extra-timeout", type=float, default=240.0, help="seconds the child job may take")
+    ap.add_argument("--extras-timeout", type=float, default=540.0,
                     help="multi-GPU tp runs: seconds the additional measurements may take after the headline one; "
                          "past it the line is printed without them and the process ends (0 = no limit)")
     ap.add_argument("--extras-stall", type=float, default=0.0, help=argparse.SUPPRESS)  # tests of the limit: idle first
@@ -127,6 +134,52 @@ def probe_main(args) -> None:
                           "scaling": "strong" if (args.parallelism == "tp" and world > 1) else "weak"}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def oneshot_child_command(args, world: int):
+    """This script again, as one rank of a second job of the same size whose tensor-parallel engine
+    asks for the in-tree all-reduce (``auto``: taken if its self-test passes, RCCL otherwise)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--prompt-len", str(args.prompt_len), "--frames", str(args.frames),
+           "--max-len", str(args.max_len), "--model", args.model,
+           # (a gloo group only bootstraps the exchange of handles: there the mode is asked for outright)
+           "--allreduce", "oneshot" if args.rehearsal else "auto",
+           "--no-dp-extra", "--no-oneshot-extra", "--extras-timeout", "120"]
+    if args.rehearsal:
+        cmd.append("--rehearsal")
+    if args.no_graph:
+        cmd.append("--no-graph")
+    if args.no_batch32:
+        cmd.append("--no-batch32")
+    return cmd
+
+
+def run_oneshot_child(args, dist, rank: int, world: int, local_rank: int, dev):
+    """The in-tree all-reduce over IPC-mapped peer buffers has only ever run between processes
+    that share one GPU.  Its first run across real links happens in a child process of every
+    rank -- its own job and process group on another port -- so that a fault there ends the child,
+    not the rank that holds the headline measurement.  Returns what rank 0's child measured."""
+    import torch
+    on_host = dist.get_backend() == "gloo"
+    port = torch.tensor([_free_port() if rank == 0 else 0], dtype=torch.int64, device="cpu" if on_host else dev)
+    dist.broadcast(port, 0)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(int(port.item())), "RANK": str(rank),
+                "WORLD_SIZE": str(world), "LOCAL_RANK": str(local_rank), "LOCAL_WORLD_SIZE": str(world),
+                "EVGPT_BENCH_CHILD": "1"})
+    r = subprocess.run(oneshot_child_command(args, world), env=env, capture_output=True, text=True,
+                       timeout=args.oneshot_extra_timeout)
+    if rank != 0:
+        return None
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"child job ended with status {r.returncode}: {r.stderr.strip()[-160:]}"}
+    got = json.loads(lines[-1])
+    out = {"tokens_per_s": got["value"], "ms_per_step": got["ms_per_step"], "tp_allreduce": got["tp_allreduce"],
+           "graph_captured": got["graph_captured"], "event_prefill_ms": got["event_prefill_ms"]}
+    if "tp_batch32" in got:
+        out["tp_batch32"] = got["tp_batch32"]
+    return out
 
 
 # --------------------------------------------------------------------- bench
@@ -317,10 +370,12 @@ def main(argv=None):
     # branch, so the group stays in step), and if the extras as a whole outlast their time limit
     # -- ranks waiting in a collective that one of them has left -- every rank prints what it
     # has and ends the process.
-    want_extras = tp and args.batch == 1 and not (args.no_batch32 and args.no_dp_extra)
+    want_oneshot = (tp and args.batch == 1 and not args.no_oneshot_extra and world <= 4
+                    and tp_allreduce in ("rccl", "gloo"))
+    want_extras = tp and args.batch == 1 and not (args.no_batch32 and args.no_dp_extra and not want_oneshot)
     if want_extras and args.extras_timeout > 0:
         def give_up():
-            for name in ("tp_batch32", "dp_replicas"):
+            for name in ("tp_batch32", "dp_replicas") + (("tp_oneshot",) if want_oneshot else ()):
                 extra.setdefault(name, {"error": f"not finished within {args.extras_timeout} s"})
             emit()
             sys.stdout.flush()
@@ -363,6 +418,17 @@ def main(argv=None):
         except Exception as e:
             extra["dp_replicas"] = {"error": str(e)[:200]}
         eng_dp = model_dp = None
+    # the same tensor-parallel measurement on the in-tree all-reduce, as a child job (at most 4 ranks:
+    # parents and children together stay well inside a node's limit on processes that hold a GPU)
+    if want_oneshot:
+        engine = model = None
+        torch.cuda.empty_cache()
+        try:
+            got = run_oneshot_child(args, dist, rank, world, local_rank, dev)
+            if got is not None:
+                extra["tp_oneshot"] = got
+        except Exception as e:
+            extra["tp_oneshot"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     if watchdog is not None:
         watchdog.cancel()
     emit()

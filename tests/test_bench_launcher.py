@@ -74,6 +74,10 @@ def test_multi_rank_flow_rehearsal_on_one_gpu(n):
     assert got["value"] > 0 and got["config"]["parallelism"] == f"tp{n}" and got["tp_allreduce"] == "gloo"
     assert "error" not in got["tp_batch32"] and got["tp_batch32"]["tokens_per_s"] > 0, got["tp_batch32"]
     assert "error" not in got["dp_replicas"] and got["dp_replicas"]["global_batch"] == n, got["dp_replicas"]
+    # the child job on the in-tree all-reduce (IPC-mapped buffers between the ranks' processes)
+    one = got["tp_oneshot"]
+    assert "error" not in one and one["tp_allreduce"] == "oneshot" and one["tokens_per_s"] > 0, one
+    assert "error" not in one["tp_batch32"], one
 
 
 @pytest.mark.gpu
@@ -93,3 +97,4 @@ def test_extras_time_limit_keeps_the_headline_line():
     got = json.loads(lines[0])
     assert got["n_gpus"] == 2 and got["value"] > 0
     assert "not finished" in got["tp_batch32"]["error"] and "not finished" in got["dp_replicas"]["error"]
+    assert "not finished" in got["tp_oneshot"]["error"]
