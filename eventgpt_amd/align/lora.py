@@ -65,6 +65,13 @@ class LoRALinear(nn.Module):
     def delta(self) -> torch.Tensor:
         return (self.lora_B.weight.float() @ self.lora_A.weight.float()) * self.scaling
 
+    def lora_delta(self, x):
+        """The low-rank update alone, ``(alpha / r) B A dropout(x)``, for a caller that computes the
+        base projection itself (several wrapped layers grouped into one GEMM); None once merged."""
+        if self.merged:
+            return None
+        return self.lora_B(self.lora_A(self.lora_dropout(x)) * self.scaling)
+
     def forward(self, x, act: Optional[str] = None, residual=None):
         plain = type(self.base) is nn.Linear
         if self.merged:

@@ -358,6 +358,44 @@ Tensor rope(const Tensor& x, const Tensor& positions, const Tensor& cos, const T
   return y;
 }
 
+// q [B,S,Hq,D], k, v [B,S,Hkv,D] = split + RoPE of a packed projection [B,S,(Hq+2Hkv)*D]
+std::vector<Tensor> rope_qkv_split(const Tensor& qkv, const Tensor& positions, const Tensor& cos, const Tensor& sin,
+                                   int64_t Hq, int64_t Hkv, int64_t D) {
+  check_bf16(qkv, "qkv"); check_f32(cos, "cos"); check_f32(sin, "sin");
+  TORCH_CHECK(qkv.dim() == 3 && qkv.size(2) == (Hq + 2 * Hkv) * D, "rope_qkv_split: qkv must be [B,S,(Hq+2Hkv)*D]");
+  const int64_t B = qkv.size(0), S = qkv.size(1);
+  TORCH_CHECK(positions.is_cuda() && positions.scalar_type() == at::kLong && positions.is_contiguous() &&
+              positions.numel() == B * S, "rope_qkv_split: positions must be a contiguous int64 [B,S] GPU tensor");
+  TORCH_CHECK(D % 16 == 0 && cos.dim() == 2 && cos.size(1) == D / 2 && sin.sizes() == cos.sizes() && cos.is_contiguous() &&
+              sin.is_contiguous(), "rope_qkv_split: cos / sin tables are [positions, D/2]");
+  Tensor q = at::empty({B, S, Hq, D}, qkv.options()), k = at::empty({B, S, Hkv, D}, qkv.options()),
+         v = at::empty({B, S, Hkv, D}, qkv.options());
+  if (qkv.numel() > 0)
+    evgpt::launch_rope_qkv(bptr(qkv), nullptr, bptr_mut(q), bptr_mut(k), bptr_mut(v),
+                           reinterpret_cast<const long long*>(positions.data_ptr<int64_t>()), cos.data_ptr<float>(),
+                           sin.data_ptr<float>(), B * S, (int)Hq, (int)Hkv, (int)D, (int)cos.size(0), false, cur_stream());
+  return {q, k, v};
+}
+
+// the packed gradient [B,S,(Hq+2Hkv)*D] of rope_qkv_split's input from the gradients of its outputs
+Tensor rope_qkv_merge(const Tensor& gq, const Tensor& gk, const Tensor& gv, const Tensor& positions, const Tensor& cos,
+                      const Tensor& sin) {
+  check_bf16(gq, "gq"); check_bf16(gk, "gk"); check_bf16(gv, "gv"); check_f32(cos, "cos"); check_f32(sin, "sin");
+  TORCH_CHECK(gq.dim() == 4 && gk.dim() == 4 && gv.sizes() == gk.sizes() && gq.size(0) == gk.size(0) &&
+              gq.size(1) == gk.size(1) && gq.size(3) == gk.size(3), "rope_qkv_merge: gq [B,S,Hq,D], gk / gv [B,S,Hkv,D]");
+  const int64_t B = gq.size(0), S = gq.size(1), Hq = gq.size(2), Hkv = gk.size(2), D = gq.size(3);
+  TORCH_CHECK(positions.is_cuda() && positions.scalar_type() == at::kLong && positions.is_contiguous() &&
+              positions.numel() == B * S, "rope_qkv_merge: positions must be a contiguous int64 [B,S] GPU tensor");
+  TORCH_CHECK(D % 16 == 0 && cos.dim() == 2 && cos.size(1) == D / 2 && sin.sizes() == cos.sizes() && cos.is_contiguous() &&
+              sin.is_contiguous(), "rope_qkv_merge: cos / sin tables are [positions, D/2]");
+  Tensor g = at::empty({B, S, (Hq + 2 * Hkv) * D}, gq.options());
+  if (g.numel() > 0)
+    evgpt::launch_rope_qkv(nullptr, bptr_mut(g), bptr_mut(gq), bptr_mut(gk), bptr_mut(gv),
+                           reinterpret_cast<const long long*>(positions.data_ptr<int64_t>()), cos.data_ptr<float>(),
+                           sin.data_ptr<float>(), B * S, (int)Hq, (int)Hkv, (int)D, (int)cos.size(0), true, cur_stream());
+  return g;
+}
+
 // --------------------------------------------------------------- attention
 void fill_strides_bshd(const Tensor& t, long long* s) {
   TORCH_CHECK(t.stride(3) == 1, "attention: head_dim must be contiguous");
@@ -1038,6 +1076,8 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("reduce_rope_kv(Tensor partial, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos0, int B, int S, int Hq, int Hkv, int D) -> ()", &reduce_rope_kv);
   m.def("swiglu(Tensor gate_up) -> Tensor", &swiglu);
   m.def("rope(Tensor x, Tensor positions, Tensor cos, Tensor sin) -> Tensor", &rope);
+  m.def("rope_qkv_split(Tensor qkv, Tensor positions, Tensor cos, Tensor sin, int Hq, int Hkv, int D) -> Tensor[]", &rope_qkv_split);
+  m.def("rope_qkv_merge(Tensor gq, Tensor gk, Tensor gv, Tensor positions, Tensor cos, Tensor sin) -> Tensor", &rope_qkv_merge);
   m.def("attention(Tensor q, Tensor k, Tensor v, bool causal, float scale, int q_offset) -> Tensor", &attention);
   m.def("attention_fwd_lse(Tensor q, Tensor k, Tensor v, bool causal, float scale, int q_offset) -> (Tensor, Tensor)", &attention_fwd_lse);
   m.def("attention_bwd(Tensor q, Tensor k, Tensor v, Tensor o, Tensor d_o, Tensor lse, bool causal, float scale, int q_offset) -> (Tensor, Tensor, Tensor)", &attention_bwd);

@@ -120,6 +120,9 @@ void launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t*
 void launch_rope_kv_prefill(const bf16_t* qkv, bf16_t* q_out, bf16_t* k_cache, bf16_t* v_cache,
                             const float* cos_tab, const float* sin_tab, const int* pos0, int B,
                             int S, int Hq, int Hkv, int D, int l_max, hipStream_t st);
+void launch_rope_qkv(const bf16_t* packed_in, bf16_t* packed_out, bf16_t* q, bf16_t* k, bf16_t* v,
+                     const long long* positions, const float* cos_tab, const float* sin_tab, long long tokens,
+                     int Hq, int Hkv, int D, int max_pos, bool merge, hipStream_t st);
 void launch_rope(const bf16_t* x, bf16_t* y, const long long* positions, const float* cos_tab,
                  const float* sin_tab, long long tokens, int H, int D, hipStream_t st);
 void launch_swiglu(const bf16_t* in, bf16_t* out, long long M, int I, hipStream_t st);

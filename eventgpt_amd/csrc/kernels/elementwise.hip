@@ -274,6 +274,68 @@ void launch_rope(const bf16_t* x, bf16_t* y, const long long* positions, const f
                      sin_tab, tokens, H, D);
 }
 
+// RoPE + split of a packed [tokens][(Hq+2Hkv)*D] projection into q [tokens][Hq][D], k and v
+// [tokens][Hkv][D] (training forward over a grouped q/k/v matrix), and its inverse for the
+// backward pass (MERGE: the three gradients are rotated back -- `sign` = -1 -- and written
+// into one packed gradient).  One launch either way instead of two RoPE launches plus three
+// strided copies / a concatenation.
+template <bool MERGE>
+__global__ __launch_bounds__(256) void rope_qkv_kernel(
+    const bf16_t* __restrict__ packed_in, bf16_t* __restrict__ packed_out, bf16_t* q, bf16_t* k, bf16_t* v,
+    const long long* __restrict__ positions, const float* __restrict__ cos_tab,
+    const float* __restrict__ sin_tab, long long tokens, int Hq, int Hkv, int D, int max_pos, float sign) {
+  const int hh = D >> 1, cph = hh >> 3;
+  const int heads = Hq + 2 * Hkv, per_tok = heads * cph;
+  const long long total = tokens * per_tok;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+    const long long t = i / per_tok;
+    const int rem = static_cast<int>(i % per_tok);
+    const int h = rem / cph, c = rem % cph;
+    const size_t po = (static_cast<size_t>(t) * heads + h) * D + c * 8;
+    bf16_t* sp;
+    if (h < Hq) sp = q + (static_cast<size_t>(t) * Hq + h) * D + c * 8;
+    else if (h < Hq + Hkv) sp = k + (static_cast<size_t>(t) * Hkv + (h - Hq)) * D + c * 8;
+    else sp = v + (static_cast<size_t>(t) * Hkv + (h - Hq - Hkv)) * D + c * 8;
+    const bf16_t* src = MERGE ? sp : packed_in + po;
+    bf16_t* dst = MERGE ? packed_out + po : sp;
+    const u32x4_t a = load16(src), bb = load16(src + hh);
+    if (h >= Hq + Hkv) {   // v: copied
+      *reinterpret_cast<u32x4_t*>(dst) = a;
+      *reinterpret_cast<u32x4_t*>(dst + hh) = bb;
+      continue;
+    }
+    long long pos = positions[t];
+    pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
+    const float* cs = cos_tab + static_cast<size_t>(pos) * hh + c * 8;
+    const float* sn = sin_tab + static_cast<size_t>(pos) * hh + c * 8;
+    u32x4_t o1, o2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float c0 = cs[2 * j], c1 = cs[2 * j + 1], s0 = sign * sn[2 * j], s1 = sign * sn[2 * j + 1];
+      const float x1l = bf16lo(a[j]), x1h = bf16hi(a[j]), x2l = bf16lo(bb[j]), x2h = bf16hi(bb[j]);
+      o1[j] = pack_bf16x2(x1l * c0 - x2l * s0, x1h * c1 - x2h * s1);
+      o2[j] = pack_bf16x2(x2l * c0 + x1l * s0, x2h * c1 + x1h * s1);
+    }
+    *reinterpret_cast<u32x4_t*>(dst) = o1;
+    *reinterpret_cast<u32x4_t*>(dst + hh) = o2;
+  }
+}
+
+void launch_rope_qkv(const bf16_t* packed_in, bf16_t* packed_out, bf16_t* q, bf16_t* k, bf16_t* v,
+                     const long long* positions, const float* cos_tab, const float* sin_tab, long long tokens,
+                     int Hq, int Hkv, int D, int max_pos, bool merge, hipStream_t st) {
+  const long long work = tokens * (Hq + 2 * Hkv) * (D / 16);
+  int blocks = static_cast<int>((work + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (merge)
+    hipLaunchKernelGGL(rope_qkv_kernel<true>, dim3(blocks), dim3(256), 0, st, packed_in, packed_out, q, k, v,
+                       positions, cos_tab, sin_tab, tokens, Hq, Hkv, D, max_pos, -1.f);
+  else
+    hipLaunchKernelGGL(rope_qkv_kernel<false>, dim3(blocks), dim3(256), 0, st, packed_in, packed_out, q, k, v,
+                       positions, cos_tab, sin_tab, tokens, Hq, Hkv, D, max_pos, 1.f);
+}
+
 // ------------------------------------------------------------------ SwiGLU
 // in: [M][2I] laid out [gate | up]; out: [M][I]
 __global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ in,

@@ -60,6 +60,43 @@ class Linear(nn.Linear):
         return ops.linear(x, self.weight, self.bias, act, residual)
 
 
+def group_frozen_weights(mods) -> Optional[torch.Tensor]:
+    """Re-home the weights of frozen projections that read the same input in ONE ``[sum N, K]``
+    matrix: each module's ``weight`` becomes a row-slice view of it (same values, same shapes, no
+    extra memory), and a forward over the group is one GEMM of the combined width instead of one
+    per projection -- a few hundred rows against 4096 columns fill barely one round of tiles, the
+    same rows against 12288 or 22016 columns run 1.3-1.5x faster per FLOP -- and the input gradient
+    one GEMM over the combined contraction instead of one per projection plus their sum.  Only for
+    plain bias-free bf16 GPU layers whose weights do not train.  Returns the matrix, or None."""
+    ws = [getattr(m, "weight", None) for m in mods]
+    for m, w in zip(mods, ws):
+        if type(m) is not Linear or m.bias is not None or w is None or w.requires_grad or not w.is_cuda \
+                or w.dtype != torch.bfloat16 or w.dim() != 2 or w.shape[1] != ws[0].shape[1] or w.shape[0] % 64:
+            return None
+    cat = torch.cat([w.detach() for w in ws], 0)
+    r = 0
+    for w in ws:
+        w.data = cat[r:r + w.shape[0]]
+        w._in_group = True
+        r += w.shape[0]
+    cat._members = ws
+    return cat
+
+
+def group_intact(cat: Optional[torch.Tensor], mods, x: torch.Tensor) -> bool:
+    """The group matrix still IS these modules' weights (none re-assigned, moved, wrapped or
+    unfrozen since) and fits the input."""
+    if cat is None or not x.is_cuda or x.dtype != cat.dtype:
+        return False
+    at, row_bytes = cat.data_ptr(), cat.shape[1] * cat.element_size()
+    for m in mods:
+        w = getattr(m, "weight", None)
+        if type(m) is not Linear or w is None or w.requires_grad or w.data_ptr() != at or w.dtype != cat.dtype:
+            return False
+        at += w.shape[0] * row_bytes
+    return True
+
+
 class LlamaAttention(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -72,14 +109,34 @@ class LlamaAttention(nn.Module):
         self.v_proj = Linear(h, self.num_kv_heads * self.head_dim, bias=False)
         self.o_proj = Linear(self.num_heads * self.head_dim, h, bias=False)
 
+    def _qkv_bases(self):
+        """q / k / v as plain layers: a low-rank wrapper (``.base`` + ``lora_delta``) counts as its base."""
+        return tuple(getattr(m, "base", m) for m in (self.q_proj, self.k_proj, self.v_proj))
+
+    def group_frozen(self) -> bool:
+        """``group_frozen_weights`` over q / k / v: one projection GEMM, split and rotated by one launch."""
+        self._w_qkv = group_frozen_weights(self._qkv_bases())
+        return self._w_qkv is not None
+
     def forward(self, x, positions, rope, past_kv, key_padding_mask, residual):
         b, s, _ = x.shape
-        q = self.q_proj(x).view(b, s, self.num_heads, self.head_dim)
-        k = self.k_proj(x).view(b, s, self.num_kv_heads, self.head_dim)
-        v = self.v_proj(x).view(b, s, self.num_kv_heads, self.head_dim)
         cos, sin = rope
-        q = ops.apply_rope(q, positions, cos, sin)
-        k = ops.apply_rope(k, positions, cos, sin)
+        w = self.__dict__.get("_w_qkv")
+        bases = self._qkv_bases() if w is not None else ()
+        if w is not None and group_intact(w, bases, x):
+            qkv = ops.linear(x, w)
+            deltas = [m.lora_delta(x) if hasattr(m, "lora_delta") else None
+                      for m in (self.q_proj, self.k_proj, self.v_proj)]
+            if any(dl is not None for dl in deltas):      # low-rank updates onto their column ranges
+                qkv = ops.add_column_blocks(qkv, deltas, [m.weight.shape[0] for m in bases])
+            q, k, v = ops.rope_qkv_split(qkv, positions, cos, sin,
+                                         self.num_heads, self.num_kv_heads, self.head_dim)
+        else:
+            q = self.q_proj(x).view(b, s, self.num_heads, self.head_dim)
+            k = self.k_proj(x).view(b, s, self.num_kv_heads, self.head_dim)
+            v = self.v_proj(x).view(b, s, self.num_kv_heads, self.head_dim)
+            q = ops.apply_rope(q, positions, cos, sin)
+            k = ops.apply_rope(k, positions, cos, sin)
         # caches are exposed in the [B, H, L, D] layout callers expect
         k_bhld, v_bhld = k.transpose(1, 2), v.transpose(1, 2)
         if past_kv is not None:
@@ -104,8 +161,18 @@ class LlamaMLP(nn.Module):
         self.up_proj = Linear(h, i, bias=False)
         self.down_proj = Linear(i, h, bias=False)
 
+    def group_frozen(self) -> bool:
+        """``group_frozen_weights`` over gate / up: their stacked rows are the ``[gate | up]`` layout the
+        activation reads, so the concatenation disappears from the forward as well."""
+        self._w_gate_up = group_frozen_weights((self.gate_proj, self.up_proj))
+        return self._w_gate_up is not None
+
     def forward(self, x, residual=None):
-        gate_up = torch.cat([self.gate_proj(x), self.up_proj(x)], dim=-1)
+        w = self.__dict__.get("_w_gate_up")
+        if w is not None and group_intact(w, (self.gate_proj, self.up_proj), x):
+            gate_up = ops.linear(x, w)
+        else:
+            gate_up = torch.cat([self.gate_proj(x), self.up_proj(x)], dim=-1)
         return self.down_proj(ops.swiglu(gate_up), residual=residual)
 
 

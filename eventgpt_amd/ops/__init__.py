@@ -93,6 +93,36 @@ def apply_rope(x, positions, cos, sin):
     return ref.apply_rope(x, positions, cos, sin)
 
 
+def add_column_blocks(y, blocks, widths):
+    """``y[..., off_i : off_i + widths[i]] += blocks[i]`` for the blocks that are not None; ``y`` is a
+    freshly computed tensor (updated in place).  Returns ``y``."""
+    if torch.is_grad_enabled() and (y.requires_grad or any(b is not None and b.requires_grad for b in blocks)):
+        return _diff().add_column_blocks(y, blocks, widths)
+    off = 0
+    for n, blk in zip(widths, blocks):
+        if blk is not None:
+            y[..., off:off + n].add_(blk)
+        off += n
+    return y
+
+
+def rope_qkv_split(qkv, positions, cos, sin, hq: int, hkv: int, d: int):
+    """``(rope(q) [B,S,hq,d], rope(k), v [B,S,hkv,d])`` from a packed q|k|v projection
+    ``[B,S,(hq+2 hkv) d]`` (the output of one GEMM over grouped q/k/v weights)."""
+    b, s = qkv.shape[:2]
+    fits = qkv.dim() == 3 and d % 16 == 0 and cos.dtype == torch.float32 and cos.dim() == 2 \
+        and positions.numel() == b * s and qkv.dtype == torch.bfloat16
+    if _use_hip(qkv) and fits:
+        q, k, v = _hip().raw.rope_qkv_split(qkv.contiguous(), positions.to(torch.long).contiguous(),
+                                            cos.contiguous(), sin.contiguous(), hq, hkv, d)
+        return q, k, v
+    if _train(qkv):
+        return _diff().rope_qkv_split(qkv, positions, cos, sin, hq, hkv, d)
+    q, k, v = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+    return (apply_rope(q.reshape(b, s, hq, d), positions, cos, sin),
+            apply_rope(k.reshape(b, s, hkv, d), positions, cos, sin), v.reshape(b, s, hkv, d))
+
+
 def attention(q, k, v, causal: bool, scale: Optional[float] = None, q_offset: int = 0,
               key_padding_mask=None):
     if _use_hip(q, k, v) and q.dtype == torch.bfloat16 and key_padding_mask is None \

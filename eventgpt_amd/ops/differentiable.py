@@ -139,18 +139,29 @@ def linear_wgrad(gy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] 
     return _raw().linear_t(gy, x, True, True, None, None, 0, False, _round64(gy.shape[0]), out)
 
 
-def enable_transposed_dgrad(module: torch.nn.Module, min_free_bytes: int = 32 << 30) -> int:
+def enable_transposed_dgrad(module: torch.nn.Module, min_free_bytes: int = 32 << 30, group: bool = True) -> int:
     """Give every FROZEN bf16 weight matrix of ``module`` a row-major copy of its transpose for the
     input-gradient product.  ``dX = dY W`` contracts over W's rows; read from ``W`` itself that is the
     K-strided operand path (transposing LDS reads, 420-660 TFLOP/s at ~840 tokens), read from
     ``W^T [K, N]`` it is the plain product the forward runs (750-880).  Only weights that do not
     train qualify (the copy would be stale after every optimizer step), and only while at least
     ``min_free_bytes`` of device memory stay free.  Returns the bytes spent.  A copy is refreshed
-    if its weight was written in place or moved since (``_version`` / ``data_ptr``)."""
+    if its weight was written in place or moved since (``_version`` / ``data_ptr``).
+    ``group``: first let every submodule that can (``group_frozen``: gate / up of an MLP) gather its
+    frozen projections in one matrix; the group then gets ONE transposed copy."""
     spent = 0
+    if group:
+        for m in module.modules():
+            if hasattr(m, "group_frozen"):
+                m.group_frozen()
+    todo = []
     for m in module.modules():
+        todo += [g for g in (m.__dict__.get(a) for a in _GROUP_ATTRS) if g is not None]
         w = getattr(m, "weight", None)
-        if not isinstance(m, torch.nn.Linear) or w is None or w.requires_grad or not _fused(w):
+        if isinstance(m, torch.nn.Linear) and w is not None and not getattr(w, "_in_group", False):
+            todo.append(w)
+    for w in todo:
+        if w.requires_grad or not _fused(w):
             continue
         n, k = w.shape
         if n % 64 or k % 8 or getattr(w, "_dgrad_t", None) is not None:
@@ -158,20 +169,45 @@ def enable_transposed_dgrad(module: torch.nn.Module, min_free_bytes: int = 32 <<
         need = w.numel() * w.element_size()
         if torch.cuda.mem_get_info(w.device)[0] - need < min_free_bytes:
             break
-        w._dgrad_t = (w.detach().t().contiguous(), w._version, w.data_ptr())
+        w._dgrad_t = (w.detach().t().contiguous(), _version_of(w), w.data_ptr())
         spent += need
     return spent
 
 
-def release_transposed_dgrad(module: torch.nn.Module) -> int:
+# module attributes that hold a group matrix (``models.llama.group_frozen_weights``)
+_GROUP_ATTRS = ("_w_gate_up", "_w_qkv")
+
+
+def _version_of(w: torch.Tensor) -> int:
+    """In-place writes so far, through the tensor itself or -- for a group matrix -- through the
+    member weights that are views of it (a view set with ``.data`` counts its own writes)."""
+    return w._version + sum(m._version for m in getattr(w, "_members", ()))
+
+
+def release_transposed_dgrad(module: torch.nn.Module, ungroup: bool = True) -> int:
     """Drop the copies ``enable_transposed_dgrad`` made (after training: they are one more copy of
-    every frozen matrix).  Returns the bytes released."""
+    every frozen matrix) and, with ``ungroup``, dissolve the weight groups it formed.  Returns the
+    bytes the copies held."""
     freed = 0
-    for p in module.parameters():
+    groups = [g for m in module.modules() for g in (m.__dict__.get(a) for a in _GROUP_ATTRS) if g is not None]
+    for p in list(module.parameters()) + groups:
         ent = getattr(p, "_dgrad_t", None)
         if ent is not None:
             freed += ent[0].numel() * ent[0].element_size()
             del p._dgrad_t
+    if ungroup:
+        # the grouped projections get their own storage back (a module moved to another device later
+        # would otherwise leave the group matrix behind on this one)
+        for m in module.modules():
+            for a in _GROUP_ATTRS:
+                cat = m.__dict__.pop(a, None)
+                if cat is None:
+                    continue
+                lo, hi = cat.data_ptr(), cat.data_ptr() + cat.numel() * cat.element_size()
+                for w in getattr(cat, "_members", ()):
+                    if lo <= w.data_ptr() < hi:
+                        w.data = w.data.clone()
+                    w._in_group = False
     return freed
 
 
@@ -180,9 +216,9 @@ def _transposed_for_dgrad(weight) -> Optional[torch.Tensor]:
     if ent is None or weight.requires_grad:
         return None
     wt, version, ptr = ent
-    if version != weight._version or ptr != weight.data_ptr():
+    if version != _version_of(weight) or ptr != weight.data_ptr():
         wt.copy_(weight.detach().t())
-        weight._dgrad_t = (wt, weight._version, weight.data_ptr())
+        weight._dgrad_t = (wt, _version_of(weight), weight.data_ptr())
     return wt
 
 
@@ -192,13 +228,12 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         k = x.shape[-1]
-        x2 = x.reshape(-1, k)
-        x2 = x2 if x2.is_contiguous() else x2.contiguous()
-        ctx.save_for_backward(x2, weight)
+        xc = x if x.is_contiguous() else x.contiguous()
+        ctx.save_for_backward(xc.view(-1, k), weight)
         ctx.has_bias = bias is not None
         from . import hip
-        y = hip.linear(x2, weight, bias)
-        return y.view(*x.shape[:-1], weight.shape[0])
+        # the kernel's own output in the input's leading shape: not a view, so a caller may update it in place
+        return hip.linear(xc, weight, bias)
 
     @staticmethod
     def backward(ctx, gy):
@@ -267,6 +302,67 @@ def apply_rope(x, positions, cos, sin):
     s = sin[positions].unsqueeze(2).to(x.dtype)
     x1, x2 = x[..., :d2], x[..., d2:]
     return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], dim=-1)
+
+
+class _AddColumnBlocks(torch.autograd.Function):
+    """``y[..., off_i : off_i + n_i] += block_i`` in place for the blocks that are given (``y`` is a
+    freshly computed projection nobody else holds).  The gradient of ``y`` is the incoming gradient
+    itself and a block's gradient is its column slice of it: no copy of the wide tensor either way."""
+
+    @staticmethod
+    def forward(ctx, y, widths, *blocks):
+        ctx.widths = widths
+        off = 0
+        for n, blk in zip(widths, blocks):
+            if blk is not None:
+                y[..., off:off + n].add_(blk)
+            off += n
+        ctx.mark_dirty(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        grads, off = [], 0
+        for i, n in enumerate(ctx.widths):
+            grads.append(g[..., off:off + n] if ctx.needs_input_grad[2 + i] else None)
+            off += n
+        return (g, None, *grads)
+
+
+def add_column_blocks(y, blocks, widths):
+    """Add ``blocks[i]`` (or nothing, for None) onto consecutive column ranges of ``y`` of the given
+    widths (low-rank updates onto their parts of a grouped projection)."""
+    return _AddColumnBlocks.apply(y, tuple(int(n) for n in widths), *blocks)
+
+
+class _RopeQKV(torch.autograd.Function):
+    """Packed ``[B,S,(Hq+2Hkv)*D]`` projection -> rotated q ``[B,S,Hq,D]``, rotated k and plain v
+    ``[B,S,Hkv,D]`` in one launch; the backward rotates the three gradients back into one packed
+    gradient in one launch (no strided copies, no concatenation)."""
+
+    @staticmethod
+    def forward(ctx, qkv, positions, cos, sin, hq, hkv, d):
+        pos = positions.to(torch.long).contiguous()
+        ctx.save_for_backward(pos, cos, sin)
+        q, k, v = _raw().rope_qkv_split(qkv.contiguous(), pos, cos, sin, hq, hkv, d)
+        return q, k, v
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv):
+        pos, cos, sin = ctx.saved_tensors
+        g = _raw().rope_qkv_merge(gq.contiguous(), gk.contiguous(), gv.contiguous(), pos, cos, sin)
+        return g, None, None, None, None, None, None
+
+
+def rope_qkv_split(qkv, positions, cos, sin, hq: int, hkv: int, d: int):
+    """``(rope(q), rope(k), v)`` from a packed q|k|v projection ``[B,S,(hq+2 hkv) d]``."""
+    b, s = qkv.shape[:2]
+    if (_fused(qkv) and qkv.dim() == 3 and d % 16 == 0 and cos.dtype == torch.float32 and cos.dim() == 2
+            and positions.numel() == b * s):
+        return _RopeQKV.apply(qkv, positions, cos.contiguous(), sin.contiguous(), hq, hkv, d)
+    q, k, v = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+    return (apply_rope(q.reshape(b, s, hq, d), positions, cos, sin),
+            apply_rope(k.reshape(b, s, hkv, d), positions, cos, sin), v.reshape(b, s, hkv, d))
 
 
 class _Attention(torch.autograd.Function):

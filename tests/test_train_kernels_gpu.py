@@ -138,6 +138,178 @@ def _attn_ref_grads(q, k, v, go, causal, q_offset):
     return o, qf.grad, kf.grad, vf.grad
 
 
+def test_frozen_gate_up_grouped_in_one_matrix(dev):
+    """Frozen gate / up projections re-homed as row-slices of one matrix: same values and gradients as
+    the two separate products, one forward GEMM and one input-gradient GEMM, one transposed copy for the
+    group; a member that trains again sends the module back to the separate path."""
+    from types import SimpleNamespace
+    from eventgpt_amd.models.llama import LlamaMLP, group_intact
+    from eventgpt_amd.ops.differentiable import enable_transposed_dgrad, release_transposed_dgrad
+    torch.manual_seed(0)
+    mlp = LlamaMLP(SimpleNamespace(hidden_size=512, intermediate_size=1408)).to(dev, torch.bfloat16)
+    for p in mlp.parameters():
+        p.requires_grad_(False)
+    before = {k: v.clone() for k, v in mlp.state_dict().items()}
+    x = _rand(2, 150, 512, dev=dev).requires_grad_(True)
+    gy = _rand(2, 150, 512, dev=dev, seed=5)
+    y0 = mlp(x)
+    y0.backward(gy)
+    dx0, x.grad = x.grad.clone(), None
+
+    spent = enable_transposed_dgrad(mlp, min_free_bytes=0)
+    w = mlp.__dict__["_w_gate_up"]
+    assert w.shape == (2 * 1408, 512) and group_intact(w, (mlp.gate_proj, mlp.up_proj), x)
+    assert mlp.gate_proj.weight.data_ptr() == w.data_ptr() and mlp.up_proj.weight.data_ptr() == w[1408:].data_ptr()
+    assert all(torch.equal(v, before[k]) for k, v in mlp.state_dict().items())
+    assert spent == 2 * (w.numel() + mlp.down_proj.weight.numel())        # one copy for the group, one for down
+    assert getattr(mlp.gate_proj.weight, "_dgrad_t", None) is None and w._dgrad_t[0].shape == (512, 2 * 1408)
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        y1 = mlp(x)
+        y1.backward(gy)
+    names = [e.name for e in prof.events()]
+    assert names.count("evgpt::linear") == 4 and "aten::cat" not in names and "evgpt::linear_t" not in names, \
+        sorted(set(n for n in names if "evgpt" in n or "cat" in n))
+    _close(y1, y0, 2e-2, 2e-2)
+    _close(x.grad, dx0, 2e-2, 2e-2)
+    # an in-place write through a member refreshes the group's transposed copy
+    with torch.no_grad():
+        mlp.up_proj.weight.mul_(0.5)
+    x.grad = None
+    mlp(x).backward(gy)
+    xf = x.detach().float().requires_grad_(True)
+    g, u = xf @ mlp.gate_proj.weight.float().t(), xf @ mlp.up_proj.weight.float().t()
+    ((torch.nn.functional.silu(g) * u) @ mlp.down_proj.weight.float().t()).backward(gy.float())
+    _close(x.grad, xf.grad, 3e-2, 3e-2)
+    assert release_transposed_dgrad(mlp, ungroup=False) == spent and getattr(w, "_dgrad_t", None) is None
+    mlp.up_proj.weight.requires_grad_(True)             # trains again: separate products
+    assert not group_intact(w, (mlp.gate_proj, mlp.up_proj), x)
+    x.grad = None
+    mlp(x).backward(gy)
+    assert mlp.up_proj.weight.grad is not None and mlp.up_proj.weight.grad.shape == (1408, 512)
+    release_transposed_dgrad(mlp)                       # dissolves the group: own storage again, same values
+    assert "_w_gate_up" not in mlp.__dict__ and mlp.up_proj.weight.data_ptr() != w[1408:].data_ptr()
+    assert torch.equal(mlp.gate_proj.weight, before["gate_proj.weight"]) and torch.equal(mlp.up_proj.weight, w[1408:])
+
+
+@pytest.mark.parametrize("hq,hkv,d", [(8, 8, 128), (8, 2, 64)])
+def test_rope_qkv_split_and_its_backward(dev, hq, hkv, d):
+    """One launch splits a packed q|k|v projection and rotates q and k: bit-equal to the separate RoPE
+    kernel on the slices; the backward (one launch) equals rotating each gradient back and concatenating."""
+    from eventgpt_amd import ops
+    from eventgpt_amd.ops import hip
+    b, s = 2, 75
+    qkv = _rand(b, s, (hq + 2 * hkv) * d, dev=dev)
+    pos = (torch.arange(s, device=dev)[None] + torch.tensor([[3], [11]], device=dev)).contiguous()
+    inv = 1.0 / (10000 ** (torch.arange(0, d, 2, device=dev).float() / d))
+    ang = torch.arange(256, device=dev).float()[:, None] * inv[None]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    q, k, v = ops.rope_qkv_split(qkv, pos, cos, sin, hq, hkv, d)
+    qs, ks, vs = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+    assert torch.equal(q, hip.raw.rope(qs.reshape(b, s, hq, d).contiguous(), pos, cos, sin))
+    assert torch.equal(k, hip.raw.rope(ks.reshape(b, s, hkv, d).contiguous(), pos, cos, sin))
+    assert torch.equal(v, vs.reshape(b, s, hkv, d))
+    x = qkv.clone().requires_grad_(True)
+    q2, k2, v2 = ops.rope_qkv_split(x, pos, cos, sin, hq, hkv, d)
+    assert type(q2.grad_fn).__name__ == "_RopeQKVBackward" and torch.equal(q2, q)
+    gq, gk, gv = _rand(*q.shape, dev=dev, seed=1), _rand(*k.shape, dev=dev, seed=2), _rand(*v.shape, dev=dev, seed=3)
+    torch.autograd.backward([q2, k2, v2], [gq, gk, gv])
+    want = torch.cat([hip.raw.rope(gq, pos, cos, -sin).reshape(b, s, -1), hip.raw.rope(gk, pos, cos, -sin).reshape(b, s, -1),
+                      gv.reshape(b, s, -1)], dim=-1)
+    assert torch.equal(x.grad, want)
+    # and against plain fp32 arithmetic
+    xf = qkv.float().requires_grad_(True)
+    qf = xf[..., :hq * d].reshape(b, s, hq, d)
+    c, sn = cos[pos].unsqueeze(2), sin[pos].unsqueeze(2)
+    q1, q2h = qf[..., :d // 2], qf[..., d // 2:]
+    qr = torch.cat([q1 * c - q2h * sn, q2h * c + q1 * sn], dim=-1)
+    _close(q, qr, 2e-2, 1e-2)
+    qr.backward(gq.float())
+    _close(x.grad[..., :hq * d], xf.grad[..., :hq * d], 2e-2, 1e-2)
+
+
+def test_frozen_qkv_grouped_in_one_matrix(dev):
+    """The attention block over grouped frozen q / k / v weights: same output and input gradient as the
+    three separate projections, with one projection GEMM and one split+RoPE launch each way."""
+    from types import SimpleNamespace
+    from eventgpt_amd.models.llama import LlamaAttention
+    from eventgpt_amd.ops.differentiable import enable_transposed_dgrad, release_transposed_dgrad
+    torch.manual_seed(0)
+    cfg = SimpleNamespace(hidden_size=512, num_attention_heads=4, num_key_value_heads=4)
+    att = LlamaAttention(cfg).to(dev, torch.bfloat16)
+    for p in att.parameters():
+        p.requires_grad_(False)
+    b, s, d = 2, 90, 128
+    x = (_rand(b, s, 512, dev=dev) * 0.5).requires_grad_(True)
+    res = _rand(b, s, 512, dev=dev, seed=7)
+    gy = _rand(b, s, 512, dev=dev, seed=5)
+    pos = torch.arange(s, device=dev)[None].expand(b, s).contiguous()
+    inv = 1.0 / (10000 ** (torch.arange(0, d, 2, device=dev).float() / d))
+    ang = torch.arange(128, device=dev).float()[:, None] * inv[None]
+    rope = (ang.cos().contiguous(), ang.sin().contiguous())
+    y0, _ = att(x, pos, rope, None, None, res)
+    y0.backward(gy)
+    dx0, x.grad = x.grad.clone(), None
+    enable_transposed_dgrad(att, min_free_bytes=0)
+    w = att.__dict__["_w_qkv"]
+    assert w.shape == (3 * 512, 512) and att.v_proj.weight.data_ptr() == w[1024:].data_ptr()
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        y1, kv = att(x, pos, rope, None, None, res)
+        y1.backward(gy)
+    names = [e.name for e in prof.events()]
+    assert names.count("evgpt::rope_qkv_split") == 1 and names.count("evgpt::rope_qkv_merge") == 1
+    assert names.count("evgpt::linear") == 4 and "evgpt::rope" not in names, sorted(set(n for n in names if "evgpt" in n))
+    assert kv[0].shape == (b, 4, s, d)
+    _close(y1, y0, 2e-2, 2e-2)
+    _close(x.grad, dx0, 3e-2, 2e-2)
+    with torch.no_grad():                       # the inference path (no autograd) takes the group as well
+        y2, _ = att(x.detach(), pos, rope, None, None, res)
+    _close(y2, y0, 2e-2, 2e-2)
+    release_transposed_dgrad(att)
+
+
+def test_low_rank_wrappers_over_grouped_qkv(dev):
+    """LoRA-wrapped q / k / v whose frozen bases are grouped: the base projection is one GEMM, the
+    low-rank updates are added onto their column ranges; output, input gradient and the adapters'
+    gradients equal the wrapped layers run one by one."""
+    from types import SimpleNamespace
+    from eventgpt_amd.align.lora import apply_lora, lora_parameters
+    from eventgpt_amd.models.llama import LlamaAttention
+    torch.manual_seed(0)
+    att = LlamaAttention(SimpleNamespace(hidden_size=512, num_attention_heads=4, num_key_value_heads=4)).to(dev, torch.bfloat16)
+    apply_lora(att, r=16, alpha=32, dropout=0.0)
+    with torch.no_grad():
+        for m in (att.q_proj, att.k_proj, att.v_proj, att.o_proj):
+            m.lora_B.weight.copy_(_rand(*m.lora_B.weight.shape, dev=dev, seed=9, scale=0.05))
+    b, s, d = 2, 70, 128
+    x = (_rand(b, s, 512, dev=dev) * 0.5).requires_grad_(True)
+    res, gy = _rand(b, s, 512, dev=dev, seed=7), _rand(b, s, 512, dev=dev, seed=5)
+    pos = torch.arange(s, device=dev)[None].expand(b, s).contiguous()
+    inv = 1.0 / (10000 ** (torch.arange(0, d, 2, device=dev).float() / d))
+    ang = torch.arange(128, device=dev).float()[:, None] * inv[None]
+    rope = (ang.cos().contiguous(), ang.sin().contiguous())
+    y0, _ = att(x, pos, rope, None, None, res)
+    y0.backward(gy)
+    want = [x.grad.clone()] + [p.grad.clone() for p in lora_parameters(att)]
+    x.grad = None
+    for p in lora_parameters(att):
+        p.grad = None
+    assert att.group_frozen() and att.__dict__["_w_qkv"].shape == (1536, 512)
+    assert att.k_proj.base.weight.data_ptr() == att.__dict__["_w_qkv"][512:].data_ptr()
+    y1, _ = att(x, pos, rope, None, None, res)
+    y1.backward(gy)
+    got = [x.grad] + [p.grad for p in lora_parameters(att)]
+    _close(y1, y0, 2e-2, 2e-2)
+    for g, w in zip(got, want):
+        assert g is not None and g.shape == w.shape
+        _close(g, w, 3e-2 * max(1.0, float(w.float().abs().max())), 3e-2)
+    att.q_proj.merge()                              # merged: the base weight (a row-slice of the group) holds the update
+    with torch.no_grad():
+        y2, _ = att(x.detach(), pos, rope, None, None, res)
+    _close(y2, y0, 3e-2, 3e-2)
+
+
 @pytest.mark.parametrize("D,H,Hkv,Sq,Sk,causal", [
     (128, 4, 4, 200, 200, True), (128, 32, 32, 840, 840, True), (64, 16, 16, 577, 577, False),
     (128, 8, 2, 130, 130, True), (64, 4, 4, 64, 64, True), (128, 4, 4, 70, 300, True), (64, 2, 1, 33, 90, False)])
