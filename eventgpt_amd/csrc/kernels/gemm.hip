@@ -256,7 +256,10 @@ __device__ __forceinline__ void buffer_to_lds16(const unsigned char* src, int by
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds, 16, voff, 0, 0, 0);
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool AT = false, bool BT = false>
+// KT: a K-contiguous operand's rows end inside the last K-tile (GemmParams::k_cols > 0).  A template
+// parameter, not a run-time test: with the extra staging path compiled into every instance the 64-row
+// configurations ran 5-15 % slower on contractions that never needed it.
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool AT = false, bool BT = false, bool KT = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   static_assert(!AT || BM == 64 || BM == 128, "K-strided A needs a 64- or 128-row tile");
   static_assert(!BT || BN == 64 || BN == 128, "K-strided W needs a 64- or 128-column tile");
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int lim_a = static_cast<int>(left_a > 0 ? left_a : 0), lim_w = static_cast<int>(left_w > 0 ? left_w : 0);
     const unsigned char* src_a = reinterpret_cast<const unsigned char*>(p.A) + adv_a;
     const unsigned char* src_w = reinterpret_cast<const unsigned char*>(p.W) + adv_w;
-    if (p.k_cols > 0 && k0 + BK > p.k_cols) {
+    if (KT && k0 + BK > p.k_cols) {
       // the one K-tile that runs past the end of a K-contiguous operand's rows (block-uniform
       // branch): chunks at or past k_cols get an offset outside the descriptor's range
       constexpr int kOut = 0x7ffffff0;
@@ -678,18 +681,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool AT = false, bool BT = false>
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool AT = false, bool BT = false, bool KT = false>
 static void launch_cfg(const GemmParams& p, hipStream_t st) {
   const int bn_out = p.glu_half ? BN / 2 : BN;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + bn_out - 1) / bn_out) * p.splitk;
   constexpr size_t smem = static_cast<size_t>(STAGES) * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES, AT, BT>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES, AT, BT, KT>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES, AT, BT>), dim3(tiles), dim3(256), smem,
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES, AT, BT, KT>), dim3(tiles), dim3(256), smem,
                      st, p);
 }
 
@@ -810,7 +813,19 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
     p.partial = splitk_ws;
   }
   GemmCfg cfg = pick_cfg(M, N, (splitk_ws && !amax_val) ? K : 0);
-  if (cfg == CFG_256x256 && p.k_cols) cfg = CFG_128x128;   // the 8-wave kernel stages whole K-tiles only
+  if (p.k_cols) {
+    // short last K-tile: the two instances compiled with the masked staging path (these are the
+    // low-rank products and other short contractions; the tile choice matters little for them)
+    if (M <= 32) launch_cfg<32, 64, 1, 4, 4, false, false, true>(p, st);
+    else launch_cfg<64, 128, 2, 2, 3, false, false, true>(p, st);
+    if (p.splitk > 1) {
+      const long long quads = (static_cast<long long>(M) * N + 3) / 4;
+      int blocks = static_cast<int>((quads + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+    }
+    return;
+  }
   // One workgroup per CU means whole rounds of 256 tiles: a grid of 304 tiles takes as long as
   // one of 512.  When the last round would be under half full (and there are few rounds for it
   // to hide in), the 8-wave kernel takes the columns that make whole rounds and the 4-wave
@@ -891,7 +906,13 @@ static void launch_t(const GemmParams& p, hipStream_t st) {
   auto tiles = [&](int bm, int bn) {
     return static_cast<long long>((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
   };
-  const bool cols_ok = (!AT || p.M % 8 == 0) && (!BT || p.N % 8 == 0) && p.k_cols == 0;
+  const bool cols_ok = (!AT || p.M % 8 == 0) && (!BT || p.N % 8 == 0);
+  if constexpr (!(AT && BT)) {
+    if (p.k_cols) {   // short last K-tile of the K-contiguous operand: the instance with the masked staging path
+      launch_cfg<64, 128, 2, 2, 3, AT, BT, true>(p, st);
+      return;
+    }
+  }
   if (p.splitk > 1) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
   else if ((g_forced_cfg == CFG_256x256 || (g_forced_cfg < 0 && use_256(p.M, p.N))) && cols_ok) launch_256<AT, BT>(p, st);
   else if (tiles(128, 128) >= 384) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
