@@ -719,6 +719,20 @@ static bool use_256(int M, int N) {
 
 static int g_forced_splitk = 0;
 
+// 768..1024 rows into a few thousand columns over a long contraction (one ~840-token sample against
+// the 4096-wide matrices with K = 11008 / 12288 / 22016): 48..128 tiles of 256x256 are a fraction of a
+// round, but with K split over the rest of the round the 8-wave kernel is ahead of every 4-wave
+// choice (benchmarks/bench_gemm_splitk256.py, TFLOP/s, 4 splits vs the best 4-wave configuration:
+// 836x4096x11008 878 vs 811, x12288 926 vs 844, x22016 1038 vs 871; at 636 rows -- three row tiles,
+// a quarter of the last one used -- it is behind, 725 vs 807).  Returns the split count, or 0.
+static int narrow_256_splits(int M, int N, int K) {
+  if (!g_use_256 || g_forced_cfg >= 0 || g_forced_splitk > 0 || M < 768 || M > 1024 || K < 8192) return 0;
+  const long long t = static_cast<long long>((M + 255) / 256) * ((N + 255) / 256);
+  if (t < 48 || t > 128) return 0;
+  const int s = static_cast<int>(256 / t);
+  return s > 4 ? 4 : s;
+}
+
 // K = 0: the caller cannot split K (argmax partials, K-strided operands)
 static GemmCfg pick_cfg(int M, int N, int K = 0) {
   if (g_forced_cfg >= 0) return static_cast<GemmCfg>(g_forced_cfg);
@@ -728,6 +742,7 @@ static GemmCfg pick_cfg(int M, int N, int K = 0) {
   // thresholds from benchmarks/bench_gemm.py on MI355X
   if (M <= 32) return tiles(32, 128) >= 256 ? CFG_32x128 : CFG_32x64;
   if (use_256(M, N)) return CFG_256x256;
+  if (K && narrow_256_splits(M, N, K) >= 2) return CFG_256x256;
   // Narrow outputs over a long contraction (a few hundred rows into 4096 columns over 11008, the
   // ViT's 4096 -> 1024 projection): the larger tile, its grid filled by splitting K (gemm_splitk)
   // instead of by shrinking the tile.  636 x 4096 x 11008: 128x128 with 3 splits 806 TFLOP/s,
@@ -757,6 +772,7 @@ int gemm_splitk(int M, int N, int K) {
   // weight-streaming shapes with a handful of rows (batched decode, verify)
   if (M > 32) {
     if (M > 1024) return 1;
+    if (!use_256(M, N) && narrow_256_splits(M, N, K) >= 2) return narrow_256_splits(M, N, K);
     const GemmCfg cfg = pick_cfg(M, N, K);
     const long long tl = cfg_tiles(cfg, M, N);
     int s = 1;   // fill the co-resident slots (2 blocks of 128x128, 3 of 64x128 per CU)
@@ -872,6 +888,7 @@ int gemm_splitk_t(int M, int N, int K) {
   if (g_forced_splitk > 0) return (K / 64) >= g_forced_splitk ? g_forced_splitk : 1;
   const long long t = static_cast<long long>((M + 127) / 128) * ((N + 127) / 128);
   if (g_forced_cfg >= 0 || M > 1024) return 1;
+  if (!use_256(M, N) && narrow_256_splits(M, N, K) >= 2) return narrow_256_splits(M, N, K);
   if (t <= 32 && K >= 2048) {   // narrow output, long contraction (input gradient of a low-rank B): as in gemm_splitk
     const long long want = 256 / t, most = K / 256;
     const int s = static_cast<int>(want < most ? want : most);
@@ -913,7 +930,8 @@ static void launch_t(const GemmParams& p, hipStream_t st) {
       return;
     }
   }
-  if (p.splitk > 1) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
+  if (p.splitk > 1 && cols_ok && !use_256(p.M, p.N) && narrow_256_splits(p.M, p.N, p.K) >= 2) launch_256<AT, BT>(p, st);
+  else if (p.splitk > 1) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
   else if ((g_forced_cfg == CFG_256x256 || (g_forced_cfg < 0 && use_256(p.M, p.N))) && cols_ok) launch_256<AT, BT>(p, st);
   else if (tiles(128, 128) >= 384) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
   else if (tiles(64, 128) >= 300) launch_cfg<64, 128, 2, 2, 3, AT, BT>(p, st);
