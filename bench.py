@@ -287,6 +287,13 @@ def main(argv=None):
     torch.manual_seed(1234 + data_seed)
     cfg, model, model_name = build_model(args, dev)
 
+    # The serving engine is built right after the model, before anything else has allocated and freed
+    # device memory: its packed weights and caches then sit in memory handed out early, and the decode
+    # step measures 1 % faster than with an engine built after the vision runs (2.675 vs 2.70 ms per token
+    # on one box, same kernels; neither dropping the allocator's cache before the build nor expandable
+    # segments nor an eager vision tower changes that).
+    engine = build_engine(args, model, dist, tp, args.batch)
+
     # ---- event prefill: raster -> CLIP preprocess -> ViT -> projector -> pool
     proc = EventImageProcessor(cfg.vision_config.image_size)
     ev = synthetic_events(seed=data_seed)
@@ -309,8 +316,6 @@ def main(argv=None):
         text = model.model.embed_tokens(text_ids)
         embeds = torch.cat([text[:35], feats.to(text.dtype), text[35:]])  # splice position of <event>
     S = embeds.shape[0]
-
-    engine = build_engine(args, model, dist, tp, args.batch)
 
     # ---- LLM prefill latency (one stream; sharded over the TP group when there is one)
     def prefill_once():

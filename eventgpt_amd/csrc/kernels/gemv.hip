@@ -614,6 +614,404 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : (B == 1 ? E
   }
 }
 
+// The one-row bf16 instance of the family: the kernel every decode step of a single stream spends its
+// time in.  Same layout, prologues and epilogues as gemv_kernel above, with the plainer schedule that
+// measures fastest for exactly this case -- the first weight chunks requested ahead of the norm's
+// operands, a loop unrolled four chunk-iterations deep, no register cap -- 7B decode step, same box and
+// same weight placement: 2.669 ms per token against 2.692 with gemv_kernel<1, ...> in its place.
+template <int P, int E, int KS>
+__global__ __launch_bounds__(GEMV_WAVES * 64, 1) void gemv_row1_kernel(GemvParams p) {
+  constexpr int B = 1, Q = 0;
+  static_assert(KS == 1 || KS == 2 || KS == 4, "KS waves per unit");
+  static_assert(E != E_LOGITS || KS == 1, "logits epilogue runs one wave per unit");
+  constexpr int UPB = GEMV_WAVES / KS;  // units per block iteration
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // LDS carve: [partials: GEMV_WAVES*R*B floats][argmax scratch][x image (P_RMSNORM)]
+  float* part = reinterpret_cast<float*>(smem);
+  constexpr int PART_BYTES = ((GEMV_WAVES * R * B * 4 + 15) / 16) * 16;
+  float* red = reinterpret_cast<float*>(smem + PART_BYTES);          // 16 floats
+  u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem + PART_BYTES + 64);  // [B][K/8]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ks = wid % KS, ub_slot = wid / KS;
+  const int nchunk = p.K >> 3;              // 16-byte chunks of one x row
+  const int nwc = Q ? (p.K >> 5) : nchunk;  // 16-byte chunks of one weight row
+  const size_t row_bytes = Q ? static_cast<size_t>(p.K >> 1) : static_cast<size_t>(p.K) * 2;
+  const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
+  const int nblk = p.K >> 6;                // scales per weight row (Q)
+  constexpr bool STAGE = (P == P_RMSNORM) || Q;  // x goes through LDS
+
+  // this wave's slice of the K range, in 16-byte weight chunks
+  const int cper = (nwc + KS - 1) / KS;
+  const int c_begin = ks * cper;
+  const int c_end = min(c_begin + cper, nwc);
+  const int n_units = (p.N + R - 1) / R;
+  const int n_ub = (n_units + UPB - 1) / UPB;
+
+  // ---------------- prologue: normalise x into LDS (fused RMSNorm) ----------------
+  // The weights do not depend on x, so the first PRE chunk-iterations of this
+  // wave's first unit are requested before the norm: the HBM round trip of the
+  // first weight bytes then overlaps the reduction instead of following it.
+  constexpr int PRE = Q ? 0 : EVGPT_GEMV_PRE;  // 4-bit: the registers go to the expansion
+  u32x4_t pre[PRE > 0 ? PRE : 1][R];
+  float pre_sc[PRE > 0 ? PRE : 1][R];
+  if constexpr (STAGE) {
+    const int u = blockIdx.x * UPB + ub_slot;
+    int row[R];
+    unit_rows<E>(p, u < n_units ? u : n_units - 1, row);
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) {
+      const int c = c_begin + lane + 64 * i;
+      const int cc = c < c_end ? c : 0;  // out-of-slice lanes load a valid address and drop it
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int rr = row[r] < p.N ? row[r] : p.N - 1;
+        pre[i][r] = load_stream16(Wb + static_cast<size_t>(rr) * row_bytes + static_cast<size_t>(cc) * 16);
+        if constexpr (Q)
+          pre_sc[i][r] = __builtin_nontemporal_load(p.absmax + static_cast<size_t>(rr) * nblk + (cc >> 1));
+      }
+    }
+  }
+  if constexpr (P == P_RMSNORM) {
+    constexpr int XC = 2;  // x chunks a thread keeps in registers between the two passes
+    if (nchunk <= XC * GEMV_WAVES * 64) {
+      u32x4_t nw[XC];
+#pragma unroll
+      for (int i = 0; i < XC; ++i) {
+        const int c = tid + i * GEMV_WAVES * 64;
+        nw[i] = c < nchunk ? load16(p.norm_w + c * 8) : u32x4_t{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        u32x4_t xv[XC];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < XC; ++i) {
+          const int c = tid + i * GEMV_WAVES * 64;
+          xv[i] = c < nchunk ? load16(p.x + (static_cast<size_t>(b) * p.K + c * 8))
+                             : u32x4_t{0, 0, 0, 0};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float lo = bf16lo(xv[i][j]), hi = bf16hi(xv[i][j]);
+            ss += lo * lo + hi * hi;
+          }
+        }
+        ss = block_sum(ss, red);
+        const float rstd = rsqrtf(ss / static_cast<float>(p.K) + p.eps);
+#pragma unroll
+        for (int i = 0; i < XC; ++i) {
+          const int c = tid + i * GEMV_WAVES * 64;
+          u32x4_t o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            // HF order: round x*rstd to bf16, then multiply by the bf16 weight
+            const float lo = bf16_to_f32(f32_to_bf16(bf16lo(xv[i][j]) * rstd)) * bf16lo(nw[i][j]);
+            const float hi = bf16_to_f32(f32_to_bf16(bf16hi(xv[i][j]) * rstd)) * bf16hi(nw[i][j]);
+            o[j] = pack_bf16x2(lo, hi);
+          }
+          if (c < nchunk) xs[b * nchunk + xs_slot<Q>(c)] = o;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        float ss = 0.f;
+        for (int c = tid; c < nchunk; c += blockDim.x) {
+          u32x4_t v = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float lo = bf16lo(v[i]), hi = bf16hi(v[i]);
+            ss += lo * lo + hi * hi;
+          }
+        }
+        ss = block_sum(ss, red);
+        const float rstd = rsqrtf(ss / static_cast<float>(p.K) + p.eps);
+        for (int c = tid; c < nchunk; c += blockDim.x) {
+          u32x4_t v = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+          u32x4_t w = load16(p.norm_w + c * 8);
+          u32x4_t o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float lo = bf16_to_f32(f32_to_bf16(bf16lo(v[i]) * rstd)) * bf16lo(w[i]);
+            const float hi = bf16_to_f32(f32_to_bf16(bf16hi(v[i]) * rstd)) * bf16hi(w[i]);
+            o[i] = pack_bf16x2(lo, hi);
+          }
+          xs[b * nchunk + xs_slot<Q>(c)] = o;
+        }
+      }
+    }
+    __syncthreads();
+  } else if constexpr (Q) {
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+      for (int c = tid; c < nchunk; c += blockDim.x)
+        xs[b * nchunk + xs_slot<Q>(c)] = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+    __syncthreads();
+  }
+
+  float best_val[B];
+  int best_idx[B];
+  if constexpr (E == E_LOGITS) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) { best_val[b] = -INFINITY; best_idx[b] = 0; }
+  }
+
+  // Epilogue operands that do not depend on the dot products are requested early, so
+  // the tail of a block is one memory round trip (the store), not a chain of them:
+  // positions here, the residual rows at the top of each unit.
+  int pos_in[B];
+  if constexpr (E == E_QKV_ROPE) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) pos_in[b] = p.rows_one_seq ? p.pos[0] + b : p.pos[b];
+  }
+
+  // block-uniform trip count: the partial-sum exchange below contains a barrier
+  for (int ub = blockIdx.x; ub < n_ub; ub += gridDim.x) {
+    const int u = ub * UPB + ub_slot;
+    const bool unit_ok = u < n_units;
+    int row[R];
+    unit_rows<E>(p, unit_ok ? u : n_units - 1, row);
+    const unsigned char* wp[R];
+    const float* sp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int rr = row[r] < p.N ? row[r] : p.N - 1;  // clamp; out-of-range rows are discarded
+      wp[r] = Wb + static_cast<size_t>(rr) * row_bytes;
+      if constexpr (Q) sp[r] = p.absmax + static_cast<size_t>(rr) * nblk;
+    }
+    float acc[R][B];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
+    bf16_t res_in[R][B];
+    if constexpr (E == E_RESIDUAL) {
+      if (lane == 0 && ks == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int b = 0; b < B; ++b)
+            res_in[r][b] = row[r] < p.N ? p.res[static_cast<size_t>(b) * p.N + row[r]] : bf16_t(0);
+      }
+    }
+
+    float cs_in[2][B], sn_in[2][B];
+    if constexpr (E == E_QKV_ROPE) {
+      if (lane == 0 && ks == 0 && row[0] < (p.n_q_heads + p.n_kv_heads) * p.head_dim) {
+        const int hh = p.head_dim >> 1, j = row[0] % p.head_dim;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          const int pc = pos_in[b] < 0 ? 0 : (pos_in[b] >= p.l_max ? p.l_max - 1 : pos_in[b]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            cs_in[i][b] = p.cos_tab[static_cast<size_t>(pc) * hh + j + i];
+            sn_in[i][b] = p.sin_tab[static_cast<size_t>(pc) * hh + j + i];
+          }
+        }
+      }
+    }
+
+    auto consume = [&](const u32x4_t (&wv)[R], const float (&sc)[R], int c) {
+      if constexpr (Q) {
+        u32x4_t xv[B][4];
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xv[b][j] = xs[b * nchunk + xs_slot<Q>(4 * c + j)];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          // one row at a time: without the fence the scheduler interleaves the four
+          // rows' expansions (64 more live registers) and the kernel spills
+          __builtin_amdgcn_sched_barrier(0);
+          float s[B];
+#pragma unroll
+          for (int b = 0; b < B; ++b) s[b] = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            unsigned int e[4];
+            w4_expand8(wv[r][j], p.code, e);
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) s[b] = dot2_bf16(e[i], xv[b][j][i], s[b]);
+          }
+#pragma unroll
+          for (int b = 0; b < B; ++b) acc[r][b] = fmaf(sc[r], s[b], acc[r][b]);
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          u32x4_t xv;
+          if constexpr (P == P_RMSNORM) xv = xs[b * nchunk + c];
+          else xv = load16(p.x + (static_cast<size_t>(b) * p.K + c * 8));
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[r][b] = dot8_bf16(wv[r], xv, acc[r][b]);
+        }
+      }
+    };
+    int c = c_begin + lane;
+    if constexpr (STAGE) {
+      if (ub == blockIdx.x) {  // the chunks requested ahead of the prologue
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+          if (c < c_end) consume(pre[i], pre_sc[i], c);
+          c += 64;
+        }
+      }
+    }
+    // bf16: 4 iterations (16 loads) in flight per lane; 4-bit: one iteration is already
+    // 2048 weights per row-quad and the expansion needs the registers
+#pragma unroll(Q ? 1 : 4)
+    for (; c < c_end; c += 64) {
+      u32x4_t wv[R];
+      float sc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        wv[r] = load_stream16(wp[r] + static_cast<size_t>(c) * 16);
+        if constexpr (Q) sc[r] = __builtin_nontemporal_load(sp[r] + (c >> 1));
+      }
+      consume(wv, sc, c);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc[r][b] = wave_sum(acc[r][b]);
+
+    if constexpr (KS > 1) {
+      // combine the KS partial sums of each unit through LDS; wave ks==0 finishes
+      __syncthreads();  // previous iteration's readers are done with `part`
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int b = 0; b < B; ++b) part[(wid * R + r) * B + b] = acc[r][b];
+      }
+      __syncthreads();
+      if (ks == 0) {
+#pragma unroll
+        for (int k2 = 1; k2 < KS; ++k2)
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int b = 0; b < B; ++b) acc[r][b] += part[((wid + k2) * R + r) * B + b];
+      }
+    }
+    if (!unit_ok || ks != 0) continue;
+
+    // ------------------------------ epilogues ------------------------------
+    if constexpr (E == E_LOGITS) {
+#pragma unroll
+      for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (row[r] < p.N) {
+            // fp32 logits: rounding them to bf16 would turn near-ties into exact
+            // ties, and a greedy decode must agree with a batched verify of it
+            const float v = acc[r][b];
+            if (lane == 0 && p.logits) p.logits[static_cast<size_t>(b) * p.N + row[r]] = v;
+            if (v > best_val[b]) { best_val[b] = v; best_idx[b] = row[r]; }
+          }
+        }
+    } else if (lane == 0) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        if constexpr (E == E_STORE) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            if (row[r] < p.N) {
+              float v = acc[r][b];
+              if (p.yf) { p.yf[static_cast<size_t>(b) * p.N + row[r]] = v; continue; }
+              if (p.bias) v += bf16_to_f32(p.bias[row[r]]);
+              v = apply_act(v, p.act);
+              p.y[static_cast<size_t>(b) * p.N + row[r]] = f32_to_bf16(v);
+            }
+          }
+        } else if constexpr (E == E_RESIDUAL) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            if (row[r] < p.N) {
+              const size_t o = static_cast<size_t>(b) * p.N + row[r];
+              float v = acc[r][b];
+              if (p.bias) v += bf16_to_f32(p.bias[row[r]]);
+              v = apply_act(v, p.act);
+              v = bf16_to_f32(f32_to_bf16(v)) + bf16_to_f32(res_in[r][b]);
+              p.y[o] = f32_to_bf16(v);
+            }
+          }
+        } else if constexpr (E == E_SWIGLU) {
+          const int half = p.N >> 1;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if (row[i] < half) {
+              const float g = bf16_to_f32(f32_to_bf16(acc[i][b]));
+              const float up = bf16_to_f32(f32_to_bf16(acc[2 + i][b]));
+              p.y[static_cast<size_t>(b) * half + row[i]] = f32_to_bf16(silu_f(g) * up);
+            }
+          }
+        } else if constexpr (E == E_QKV_ROPE) {
+          const int hd = p.head_dim, hh = hd >> 1;
+          const int q_rows = p.n_q_heads * hd, k_rows = p.n_kv_heads * hd;
+          // the position is a device counter: clamp it into the cache so a
+          // sequence that ran past its capacity overwrites the last slot
+          // instead of writing outside the allocation
+          const int pos_raw = pos_in[b];
+          const int pos = pos_raw < 0 ? 0 : (pos_raw >= p.l_max ? p.l_max - 1 : pos_raw);
+          const int slot = p.rows_one_seq ? 0 : b;   // cache slot of this row's sequence
+          // a row past the cache of a multi-row pass is dropped, never wrapped onto a live slot
+          const bool kv_ok = !p.rows_one_seq || (pos_raw >= 0 && pos_raw < p.l_max);
+          if (row[0] < q_rows + k_rows) {
+            const int h_all = row[0] / hd, j = row[0] % hd;  // j < hh
+            bf16_t* dst;
+            if (h_all < p.n_q_heads) {
+              dst = p.q_out + static_cast<size_t>(b) * q_rows + h_all * hd;
+            } else {
+              if (!kv_ok) continue;
+              const int h = h_all - p.n_q_heads;
+              dst = p.k_cache + ((static_cast<size_t>(slot) * p.n_kv_heads + h) * p.l_max + pos) * hd;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const float c = cs_in[i][b], s = sn_in[i][b];
+              const float x1 = bf16_to_f32(f32_to_bf16(acc[i][b]));
+              const float x2 = bf16_to_f32(f32_to_bf16(acc[2 + i][b]));
+              dst[j + i] = f32_to_bf16(x1 * c - x2 * s);
+              dst[j + i + hh] = f32_to_bf16(x2 * c + x1 * s);
+            }
+          } else {
+            if (!kv_ok) continue;
+            const int vr = row[0] - q_rows - k_rows;
+            const int h = vr / hd, j = vr % hd;
+            bf16_t* dst = p.v_cache + ((static_cast<size_t>(slot) * p.n_kv_heads + h) * p.l_max + pos) * hd;
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[j + r] = f32_to_bf16(acc[r][b]);
+          }
+        }
+      }
+    }
+  }
+
+  if constexpr (E == E_LOGITS) {
+    // block-level argmax partial: (value, lowest index on ties)
+    float* sv = part;                                  // [GEMV_WAVES][B]
+    int* si = reinterpret_cast<int*>(part) + GEMV_WAVES * B;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) { sv[wid * B + b] = best_val[b]; si[wid * B + b] = best_idx[b]; }
+    }
+    __syncthreads();
+    if (tid < B) {
+      float bv = sv[tid];
+      int bi = si[tid];
+      for (int w = 1; w < GEMV_WAVES; ++w)
+        if (sv[w * B + tid] > bv || (sv[w * B + tid] == bv && si[w * B + tid] < bi)) {
+          bv = sv[w * B + tid]; bi = si[w * B + tid];
+        }
+      p.part_val[tid * gridDim.x + blockIdx.x] = bv;
+      p.part_idx[tid * gridDim.x + blockIdx.x] = bi;
+    }
+  }
+}
+
 static int g_forced_ks = 0;
 void gemv_force_ks(int ks) { g_forced_ks = ks; }   // 0 = automatic; for tuning runs
 
@@ -637,10 +1035,8 @@ static int pick_ks(int N, int K) {
   const int ek = env_ks(N, K);
   if (ek == 1 || ek == 2 || ek == 4) return ek;
   const int units = (N + R - 1) / R;
-  // a wave's slice of 2048 weights per row is exactly UNROLL(4) iterations of one round trip:
-  // a 4096-deep projection with few rows (o_proj) takes 2 waves per unit, not 4 (measured
-  // 2.86 vs 2.90 ms per 7B token); deeper ones (down_proj, 11008) keep 4
-  if (K <= 4096 && units * 2 >= 2048 && units < 3000) return 2;
+  // (two waves per unit for the 4096-deep, 4096-row o_proj looked ahead in one set of runs and
+  // measures behind with the weights placed alike: 2.701 vs 2.692 ms per 7B token; four it is)
   if (units >= 6000) return 1;
   if (units >= 3000) return 2;
   return 4;
@@ -672,7 +1068,10 @@ static void launch_bk(const GemvParams& p, int B, hipStream_t st) {
   const int full = gemv_grid(p.N, KS);
   dim3 g(Q && full > cap4 ? cap4 : full), b(GEMV_WAVES * 64);
   switch (B) {
-    case 1: hipLaunchKernelGGL((gemv_kernel<1, P, E, KS, Q>), g, b, smem, st, p); break;
+    case 1:
+      if constexpr (Q == 0) hipLaunchKernelGGL((gemv_row1_kernel<P, E, KS>), g, b, smem, st, p);
+      else hipLaunchKernelGGL((gemv_kernel<1, P, E, KS, Q>), g, b, smem, st, p);
+      break;
     case 2: hipLaunchKernelGGL((gemv_kernel<2, P, E, KS, Q>), g, b, smem, st, p); break;
     case 3: hipLaunchKernelGGL((gemv_kernel<3, P, E, KS, Q>), g, b, smem, st, p); break;
     case 4:
