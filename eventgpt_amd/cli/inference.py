@@ -103,6 +103,10 @@ def run(argv: Optional[Sequence[str]] = None) -> str:
         tokenizer.add_tokens([DEFAULT_EV_START_TOKEN, DEFAULT_EV_END_TOKEN], special_tokens=True)
     model.resize_token_embeddings(len(tokenizer))
     model.eval()
+    if device.type == "cuda" and dtype == torch.bfloat16 and args.num_beams == 1:
+        # the serving engine packs its weights and caches now, before the vision tower has allocated
+        # and freed anything: decode steps measure 1 % faster on memory handed out this early
+        model.engine()
 
     event_processor = model.get_visual_tower().event_processor
     prompt = prepare_event_prompt(args.query, args.conv_mode)
