@@ -1030,13 +1030,19 @@ static int env_ks(int N, int K) {
 }
 
 // waves-per-unit so that the launch has >= ~6000 waves (24 per CU)
-static int pick_ks(int N, int K) {
+static int pick_ks(int N, int K, bool one_row_bf16) {
   if (g_forced_ks == 1 || g_forced_ks == 2 || g_forced_ks == 4) return g_forced_ks;
   const int ek = env_ks(N, K);
   if (ek == 1 || ek == 2 || ek == 4) return ek;
   const int units = (N + R - 1) / R;
-  // (two waves per unit for the 4096-deep, 4096-row o_proj looked ahead in one set of runs and
-  // measures behind with the weights placed alike: 2.701 vs 2.692 ms per 7B token; four it is)
+  // One bf16 row (single-stream decode): four waves per unit for every matrix of the 7B decoder,
+  // also the 12288- and 22016-row ones that two waves per unit would already spread over 6000+
+  // waves.  7B decode step on one box with the weights placed alike, ms per token: qkv 2 -> 4 waves
+  // 2.681 -> 2.659, gate/up 2 -> 4 2.681 -> 2.653, both 2.665 -> 2.621; one wave per unit 2.72 / 2.80;
+  // two for down_proj 2.77, two for o_proj 2.74.  More rows or 4-bit weights go the other way
+  // (two rows 3.17 -> 3.40 ms per verify pass, three 3.47 -> 4.08, NF4 step 1.766 -> 1.789) and keep
+  // the wave-count rule.
+  if (one_row_bf16 && units < 6000) return 4;
   if (units >= 6000) return 1;
   if (units >= 3000) return 2;
   return 4;
@@ -1047,13 +1053,14 @@ static int gemv_grid(int N, int ks) {
   const int upb = GEMV_WAVES / ks;
   const int blocks = (units + upb - 1) / upb;
   // 8 blocks per CU are resident.  Measured on MI355X (7B decode step): letting
-  // the dispatcher hand out up to 4096 one-unit blocks beats a 2048-block grid
-  // whose blocks loop (2.79 vs 2.82 ms per token), and an even split of units
-  // over fewer blocks is slower than both.  EVGPT_GEMV_CAP overrides for tuning.
+  // the dispatcher hand out one-unit blocks beats a 2048-block grid whose blocks loop
+  // (2.79 vs 2.82 ms per token; 5504 one-unit blocks for gate/up vs 4096 looping ones
+  // 2.616 vs 2.621), and an even split of units over fewer blocks is slower than both.
+  // EVGPT_GEMV_CAP overrides for tuning.
   static const int cap = [] {
     const char* e = getenv("EVGPT_GEMV_CAP");
     const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 4096;
+    return v > 0 ? v : 8192;
   }();
   return blocks < cap ? blocks : cap;
 }
@@ -1091,14 +1098,14 @@ static void launch_b(const GemvParams& p, int B, hipStream_t st) {
     // work (and the share of a block's prologue) comparable; measured on the 7B decode
     // step: 2.12 ms with the bf16 choice, 1.92 ms with half (EVGPT_W4_KS_SHIFT to tune)
     static const int shift = [] { const char* e = getenv("EVGPT_W4_KS_SHIFT"); return e ? atoi(e) : 1; }();
-    int ks = pick_ks(p.N, p.K) >> shift;
+    int ks = pick_ks(p.N, p.K, false) >> shift;
     switch (ks < 1 ? 1 : ks) {
       case 1: launch_bk<P, E, 1, 1>(p, B, st); break;
       case 2: launch_bk<P, E, 2, 1>(p, B, st); break;
       default: launch_bk<P, E, 4, 1>(p, B, st); break;
     }
   } else {
-    switch (pick_ks(p.N, p.K)) {
+    switch (pick_ks(p.N, p.K, B == 1)) {
       case 1: launch_bk<P, E, 1, 0>(p, B, st); break;
       case 2: launch_bk<P, E, 2, 0>(p, B, st); break;
       default: launch_bk<P, E, 4, 0>(p, B, st); break;
