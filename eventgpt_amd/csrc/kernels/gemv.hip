@@ -618,9 +618,22 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : (B == 1 ? E
 // time in.  Same layout, prologues and epilogues as gemv_kernel above, with the plainer schedule that
 // measures fastest for exactly this case -- the first weight chunks requested ahead of the norm's
 // operands, a loop unrolled four chunk-iterations deep, no register cap -- 7B decode step, same box and
-// same weight placement: 2.669 ms per token against 2.692 with gemv_kernel<1, ...> in its place.
+// same weight placement: 2.669 ms per token against 2.692 with gemv_kernel<1, ...> in its place (and
+// 2.621 against 2.729 with four waves per unit for every matrix).
+// Build variants run back to back on one box (7B decode step, ms per token; -DEVGPT_ROW1_...):
+// PRE / UNROLL / OCC = 1 / 4 / 1: 2.619; PRE 0: 2.765; PRE 2: 2.674; UNROLL 2: 2.639; UNROLL 8: 2.625;
+// OCC 2: 2.620.
+#ifndef EVGPT_ROW1_PRE
+#define EVGPT_ROW1_PRE 1      // weight chunk-iterations requested ahead of the fused norm
+#endif
+#ifndef EVGPT_ROW1_UNROLL
+#define EVGPT_ROW1_UNROLL 4   // chunk-iterations the main loop is unrolled by
+#endif
+#ifndef EVGPT_ROW1_OCC
+#define EVGPT_ROW1_OCC 1      // blocks per CU the register budget must admit (1: no cap)
+#endif
 template <int P, int E, int KS>
-__global__ __launch_bounds__(GEMV_WAVES * 64, 1) void gemv_row1_kernel(GemvParams p) {
+__global__ __launch_bounds__(GEMV_WAVES * 64, EVGPT_ROW1_OCC) void gemv_row1_kernel(GemvParams p) {
   constexpr int B = 1, Q = 0;
   static_assert(KS == 1 || KS == 2 || KS == 4, "KS waves per unit");
   static_assert(E != E_LOGITS || KS == 1, "logits epilogue runs one wave per unit");
@@ -651,7 +664,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, 1) void gemv_row1_kernel(GemvParam
   // The weights do not depend on x, so the first PRE chunk-iterations of this
   // wave's first unit are requested before the norm: the HBM round trip of the
   // first weight bytes then overlaps the reduction instead of following it.
-  constexpr int PRE = Q ? 0 : EVGPT_GEMV_PRE;  // 4-bit: the registers go to the expansion
+  constexpr int PRE = EVGPT_ROW1_PRE;  // 4-bit: the registers go to the expansion
   u32x4_t pre[PRE > 0 ? PRE : 1][R];
   float pre_sc[PRE > 0 ? PRE : 1][R];
   if constexpr (STAGE) {
@@ -860,7 +873,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, 1) void gemv_row1_kernel(GemvParam
     }
     // bf16: 4 iterations (16 loads) in flight per lane; 4-bit: one iteration is already
     // 2048 weights per row-quad and the expansion needs the registers
-#pragma unroll(Q ? 1 : 4)
+#pragma unroll(EVGPT_ROW1_UNROLL)
     for (; c < c_end; c += 64) {
       u32x4_t wv[R];
       float sc[R];
