@@ -857,6 +857,7 @@ std::tuple<Tensor, Tensor> linear_argmax_partials(const Tensor& x, const Tensor&
 
 void gemm_force_config(int64_t cfg) { evgpt::gemm_force_config((int)cfg); }
 void gemm_enable_256(bool on) { evgpt::gemm_enable_256(on); }
+void attn_force_groups(int64_t g) { evgpt::attn_force_groups((int)g); }
 void attn_enable_wide(int64_t mode) { evgpt::attn_enable_wide((int)mode); }
 void attn_wide4_min_rows(int64_t rows) { evgpt::attn_wide4_min_rows((int)rows); }
 void gemm_force_splitk(int64_t sk) { evgpt::gemm_force_splitk((int)sk); }
@@ -1111,6 +1112,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("clip_preprocess(Tensor img, Tensor hstart, Tensor hcount, Tensor hweight, Tensor vstart, Tensor vcount, Tensor vweight, int S, int resize_h, int resize_w, int top, int left, float[] mean, float[] stdv) -> Tensor", &clip_preprocess);
   m.def("gemm_force_config(int cfg) -> ()", &gemm_force_config);
   m.def("gemm_enable_256(bool on) -> ()", &gemm_enable_256);
+  m.def("attn_force_groups(int groups) -> ()", &attn_force_groups);
   m.def("attn_enable_wide(int mode) -> ()", &attn_enable_wide);
   m.def("attn_wide4_min_rows(int rows) -> ()", &attn_wide4_min_rows);
   m.def("gemm_force_splitk(int sk) -> ()", &gemm_force_splitk);

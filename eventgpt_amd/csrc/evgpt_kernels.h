@@ -58,6 +58,7 @@ void launch_sumsq(const void* x, bool bf16, long long n, float* part, float* acc
 // ---- gemm.hip
 int gemm_argmax_partials(int M, int N);
 void gemm_force_config(int cfg);  // -1 = automatic; for tuning runs
+void attn_force_groups(int g);      // key-tile groups per 64-row attention block: 0 by shape (default), 1, 2
 void attn_wide4_min_rows(int rows); // fewest query rows that take the 128-row wide blocks
 void attn_enable_wide(int mode);   // 128-query-row prefill attention: 0 never, 1 by shape (default), 2 always
 void gemm_enable_256(bool on);    // the 256 x 256 8-wave kernel for large GEMMs (default on)

@@ -43,18 +43,26 @@ struct AttnParams {
                                 // scaled-log2 domain (max + log2(sum)); the backward recomputes P from it
 };
 
-template <int D, bool CAUSAL, bool SPLIT = false>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
+// GROUPS = 2: the block is two such groups of 4 waves over the SAME 64 query rows; group 0 takes the
+// even key tiles of the block's range and group 1 the odd ones, each through its own K / V tile
+// buffers, and group 1's running (max, sum, O) is merged into group 0's at the end through LDS.  A
+// few hundred query rows of a few heads are fewer blocks than CUs, each a serial chain over its key
+// tiles; two groups halve the chain and double the waves (used for the ViT, see launch_attn_prefill).
+template <int D, bool CAUSAL, bool SPLIT = false, int GROUPS = 1>
+__global__ __launch_bounds__(256 * GROUPS) void attn_prefill_kernel(AttnParams p) {
   constexpr int CPR = D / 8;                  // 16-byte chunks per row
   constexpr int TILE_BYTES = TK * D * 2;
   constexpr int LD_PER_THREAD = TK * CPR / 256;  // chunks each thread stages per tile
   constexpr int KS = D / 32;                  // k-steps of the QK^T product
   constexpr int DT = D / 16;                  // 16-wide output column tiles
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
-  unsigned char* k_lds = lds;
-  unsigned char* v_lds = lds + TILE_BYTES;
+  static_assert(GROUPS == 1 || GROUPS == 2, "one or two groups of four waves");
+  static_assert(GROUPS == 1 || (DT * 4 + 2) * 256 * 4 <= GROUPS * 2 * TILE_BYTES, "merge buffer fits the tile buffers");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[GROUPS * 2 * TILE_BYTES];
+  const int grp = GROUPS == 1 ? 0 : static_cast<int>(threadIdx.x >> 8);
+  unsigned char* k_lds = lds + grp * 2 * TILE_BYTES;
+  unsigned char* v_lds = k_lds + TILE_BYTES;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;   // within the group
   const int fr = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.Hq / p.Hkv);
@@ -201,25 +209,58 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnParams p) {
     }
   };
 
-  if (t_begin < ntiles) prefetch(kreg[0], vreg[0], t_begin);
-  if (t_begin + 1 < ntiles) prefetch(kreg[1], vreg[1], t_begin + 1);
-  for (int t = t_begin; t < ntiles; t += 2) {
+  // this group's tiles: first, first + GROUPS, ...; the trip count is group 0's (block-uniform:
+  // the loop contains barriers), a group past its last tile only keeps step
+  const int first = t_begin + grp;
+  const int n_mine = first < ntiles ? (ntiles - first + GROUPS - 1) / GROUPS : 0;
+  const int n_iter = t_begin < ntiles ? (ntiles - t_begin + GROUPS - 1) / GROUPS : 0;
+  if (0 < n_mine) prefetch(kreg[0], vreg[0], first);
+  if (1 < n_mine) prefetch(kreg[1], vreg[1], first + GROUPS);
+  for (int k = 0; k < n_iter; k += 2) {
     __syncthreads();
-    commit(kreg[0], vreg[0]);
+    if (k < n_mine) commit(kreg[0], vreg[0]);
     __syncthreads();
-    if (t + 2 < ntiles) prefetch(kreg[0], vreg[0], t + 2);
-    if (wave_active) compute(t);
-    if (t + 1 >= ntiles) break;
+    if (k + 2 < n_mine) prefetch(kreg[0], vreg[0], first + GROUPS * (k + 2));
+    if (wave_active && k < n_mine) compute(first + GROUPS * k);
+    if (k + 1 >= n_iter) break;
     __syncthreads();
-    commit(kreg[1], vreg[1]);
+    if (k + 1 < n_mine) commit(kreg[1], vreg[1]);
     __syncthreads();
-    if (t + 3 < ntiles) prefetch(kreg[1], vreg[1], t + 3);
-    if (wave_active) compute(t + 1);
+    if (k + 3 < n_mine) prefetch(kreg[1], vreg[1], first + GROUPS * (k + 3));
+    if (wave_active && k + 1 < n_mine) compute(first + GROUPS * (k + 1));
   }
 
   // ---- finalise: l is a per-lane partial over this lane's key slots
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
+  if constexpr (GROUPS == 2) {
+    // group 1 hands its state over in lane-private columns of the (now idle) tile buffers; lane
+    // (wave, lane) of group 0 holds the same query row and output columns as its counterpart
+    __syncthreads();
+    float* xch = reinterpret_cast<float*>(lds);
+    const int col = tid;   // wave * 64 + lane within the group
+    if (grp == 1) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xch[(dt * 4 + r) * 256 + col] = o[dt][r];
+      xch[(DT * 4) * 256 + col] = m;
+      xch[(DT * 4 + 1) * 256 + col] = l;
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    const float m1 = xch[(DT * 4) * 256 + col], l1 = xch[(DT * 4 + 1) * 256 + col];
+    const float mn = fmaxf(m, m1);
+    const float msafe = mn == -INFINITY ? 0.f : mn;
+    const float a0 = __builtin_amdgcn_exp2f((m - msafe) * p.scale_log2e);    // -inf -> 0
+    const float a1 = __builtin_amdgcn_exp2f((m1 - msafe) * p.scale_log2e);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[dt][r] = o[dt][r] * a0 + xch[(dt * 4 + r) * 256 + col] * a1;
+    l = l * a0 + l1 * a1;
+    m = mn;
+  }
   if (SPLIT) {
     if (qi < p.Sq) {
       const long long slot = ((static_cast<long long>(b) * p.Hq + h) * p.nsplit + blockIdx.x) * p.Sq + qi;
@@ -527,6 +568,8 @@ __global__ __launch_bounds__(D) void attn_split_combine_kernel(AttnParams p) {
   op[d] = f32_to_bf16(l > 0.f ? acc / l : 0.f);
 }
 
+static int g_attn_groups = 0;  // key-tile groups per 64-row block: 0 = by shape, 1 / 2 = forced (tests, tuning)
+void attn_force_groups(int g) { g_attn_groups = g; }
 static int g_attn_wide = 1;   // 0 = never, 1 = by shape, 2 = whenever the strides allow (tests, tuning)
 static int g_attn_wide4_min_rows = 1400;  // fewest query rows that take the 128-row blocks (mode 1): measured crossover 1300-1500 (1024 rows 18.3 vs 18.0 ms per 7B prefill, 1500 rows 25.9 vs 26.2; 636 rows 12.6 vs 12.3, ViT frame 2.50 vs 2.24)
 void attn_enable_wide(int mode) { g_attn_wide = mode; }
@@ -593,6 +636,25 @@ void launch_attn_prefill(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16
     return;
   }
   dim3 grid((Sq + 63) / 64, Hq, B);
+  // Two key-tile groups per block for the ViT's shape class -- head_dim 64, non-causal, so few blocks
+  // that half the chip idles (577 tokens x 16 heads: 160) -- while all blocks are resident at once:
+  // 12.3 -> 9.9 us per layer.  Causal head_dim-128 blocks do not gain (636 tokens x 32 heads: 23.9 ->
+  // 25.1 us, 836: 30.4 -> 33.7): they are bound by the LDS pipe, not by the chain over their key
+  // tiles, and the diagonal splits unevenly (benchmarks/bench_attn_groups.py).
+  const long long nblocks = static_cast<long long>(grid.x) * Hq * B;
+  const bool two = g_attn_groups == 2 ||
+                   (g_attn_groups == 0 && D == 64 && !causal && nblocks <= 512 && Sk >= 4 * TK);
+  if (two) {
+    dim3 block2(512);
+    if (D == 128) {
+      if (causal) hipLaunchKernelGGL((attn_prefill_kernel<128, true, false, 2>), grid, block2, 0, st, p);
+      else hipLaunchKernelGGL((attn_prefill_kernel<128, false, false, 2>), grid, block2, 0, st, p);
+    } else {
+      if (causal) hipLaunchKernelGGL((attn_prefill_kernel<64, true, false, 2>), grid, block2, 0, st, p);
+      else hipLaunchKernelGGL((attn_prefill_kernel<64, false, false, 2>), grid, block2, 0, st, p);
+    }
+    return;
+  }
   if (D == 128) {
     if (causal) hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((attn_prefill_kernel<128, false>), grid, block, 0, st, p);
