@@ -221,3 +221,53 @@ def test_sampler_top_k_then_top_p_cpu():
     for _ in range(40):
         pick = ref.sample_top_p(wide, 2.0, 1.0, g, top_k=5)
         assert all(int(pick[b]) in keep[b].tolist() for b in range(4))
+
+
+def test_rope_qkv_split_and_column_blocks_on_cpu():
+    """The packed q|k|v helpers the grouped attention path uses have plain-tensor fallbacks: the split +
+    RoPE equals RoPE on the separate slices, and low-rank blocks added onto column ranges get exactly
+    their slice of the gradient."""
+    import torch
+    from eventgpt_amd import ops
+    torch.manual_seed(0)
+    b, s, hq, hkv, d = 2, 7, 4, 2, 16
+    qkv = torch.randn(b, s, (hq + 2 * hkv) * d, requires_grad=True)
+    pos = torch.arange(s)[None].expand(b, s).contiguous()
+    inv = 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))
+    ang = torch.arange(32).float()[:, None] * inv[None]
+    cos, sin = ang.cos(), ang.sin()
+    q, k, v = ops.rope_qkv_split(qkv, pos, cos, sin, hq, hkv, d)
+    qs, ks, vs = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+    assert torch.allclose(q, ops.apply_rope(qs.reshape(b, s, hq, d), pos, cos, sin))
+    assert torch.allclose(k, ops.apply_rope(ks.reshape(b, s, hkv, d), pos, cos, sin))
+    assert torch.equal(v, vs.reshape(b, s, hkv, d))
+    (q.sum() + 2 * k.sum() + 3 * v.sum()).backward()
+    assert qkv.grad is not None and torch.allclose(qkv.grad[..., -hkv * d:], torch.full((b, s, hkv * d), 3.0))
+
+    y = torch.randn(b, s, 24, requires_grad=True)
+    d0, d2 = torch.randn(b, s, 8, requires_grad=True), torch.randn(b, s, 4, requires_grad=True)
+    base = y * 1.0                                      # a fresh tensor the helper may update in place
+    out = ops.add_column_blocks(base, [d0, None, d2], [8, 12, 4])
+    want = y.detach().clone()
+    want[..., :8] += d0.detach()
+    want[..., 20:] += d2.detach()
+    assert torch.allclose(out, want)
+    g = torch.randn_like(out)
+    out.backward(g)
+    assert torch.allclose(y.grad, g) and torch.allclose(d0.grad, g[..., :8]) and torch.allclose(d2.grad, g[..., 20:])
+    with torch.no_grad():
+        out2 = ops.add_column_blocks(y.detach().clone(), [d0, None, d2], [8, 12, 4])
+    assert torch.allclose(out2, want)
+
+
+def test_group_frozen_weights_is_a_gpu_feature():
+    """On CPU tensors nothing is grouped and the attention / MLP blocks run their separate projections."""
+    import torch
+    from types import SimpleNamespace
+    from eventgpt_amd.models.llama import LlamaMLP, group_frozen_weights
+    mlp = LlamaMLP(SimpleNamespace(hidden_size=64, intermediate_size=128))
+    for p in mlp.parameters():
+        p.requires_grad_(False)
+    assert group_frozen_weights((mlp.gate_proj, mlp.up_proj)) is None and not mlp.group_frozen()
+    x = torch.randn(2, 5, 64)
+    assert mlp(x).shape == (2, 5, 64)
