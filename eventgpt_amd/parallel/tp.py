@@ -259,8 +259,20 @@ class TensorParallelEngine(GenerationEngine):
                     # sized for a full cache of rows (larger packs take the library collective)
                     rows = min(max(self.l_max, self.PACK_ROWS), 16384)
                     self.twoshot = comm.TwoShotAllReduce(self.tp_group, dev, rows * self.H)
+                    torch.cuda.synchronize(dev)
+                    dist.barrier(group=self.tp_group)      # every rank's buffers are mapped before the first push
                 else:
                     ar.close()
+
+    def _capture_or_eager(self, fn):
+        """A captured step is first replayed by ranks that finished capturing at different times.
+        The library collective waits for the late ones as long as it takes; the in-tree all-reduce
+        waits a bounded number of polls, so with it the ranks leave the capture together."""
+        g = super()._capture_or_eager(fn)
+        if self.oneshot is not None and self.tp_world > 1:
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.tp_group)
+        return g
 
     def _setup_parallel(self) -> None:
         g = self._group_arg
