@@ -113,11 +113,16 @@ Tensor linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bia
   } else {
     const int sk = evgpt::gemm_splitk((int)M, (int)N, (int)K);
     Tensor ws;
-    if (sk > 1) ws = at::empty({sk * M * N}, x.options().dtype(at::kFloat));
+    if (sk > 1) {
+      ws = at::empty({sk * M * N}, x.options().dtype(at::kFloat));
+    } else {
+      const int64_t tail = evgpt::gemm_tail_ws_floats((int)M, (int)N, (int)K);
+      if (tail > 0) ws = at::empty({tail}, x.options().dtype(at::kFloat));
+    }
     evgpt::launch_gemm_bf16(bptr(x), bptr(w), out_f32 ? nullptr : bptr_mut(y),
                             out_f32 ? y.data_ptr<float>() : nullptr, bptr_opt(bias),
                             bptr_opt(res), (int)M, (int)N, (int)K, (int)K, (int)K, (int)N, (int)act,
-                            nullptr, nullptr, sk > 1 ? ws.data_ptr<float>() : nullptr, sk, st);
+                            nullptr, nullptr, ws.defined() ? ws.data_ptr<float>() : nullptr, sk, st);
   }
   return y;
 }
@@ -858,6 +863,7 @@ std::tuple<Tensor, Tensor> linear_argmax_partials(const Tensor& x, const Tensor&
 void gemm_force_config(int64_t cfg) { evgpt::gemm_force_config((int)cfg); }
 void gemm_enable_256(bool on) { evgpt::gemm_enable_256(on); }
 void attn_force_groups(int64_t g) { evgpt::attn_force_groups((int)g); }
+void gemm_enable_tail_splitk(bool on) { evgpt::gemm_enable_tail_splitk(on); }
 void attn_enable_wide(int64_t mode) { evgpt::attn_enable_wide((int)mode); }
 void attn_wide4_min_rows(int64_t rows) { evgpt::attn_wide4_min_rows((int)rows); }
 void gemm_force_splitk(int64_t sk) { evgpt::gemm_force_splitk((int)sk); }
@@ -1113,6 +1119,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("gemm_force_config(int cfg) -> ()", &gemm_force_config);
   m.def("gemm_enable_256(bool on) -> ()", &gemm_enable_256);
   m.def("attn_force_groups(int groups) -> ()", &attn_force_groups);
+  m.def("gemm_enable_tail_splitk(bool on) -> ()", &gemm_enable_tail_splitk);
   m.def("attn_enable_wide(int mode) -> ()", &attn_enable_wide);
   m.def("attn_wide4_min_rows(int rows) -> ()", &attn_wide4_min_rows);
   m.def("gemm_force_splitk(int sk) -> ()", &gemm_force_splitk);

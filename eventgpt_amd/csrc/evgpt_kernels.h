@@ -75,6 +75,8 @@ void launch_gemm_bf16_t(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, 
 int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M, int N, int K,
                         int lda, int ldw, hipStream_t st);
 int gemm_splitk(int M, int N, int K);   // planned split count (1 = none); ws = splitk*M*N floats
+long long gemm_tail_ws_floats(int M, int N, int K);   // unsplit GEMMs: workspace the last-round K split wants (0: none)
+void gemm_enable_tail_splitk(bool on);
 void gemm_force_splitk(int sk);         // 0 = automatic; for tuning runs
 
 // ---- event_ops.hip

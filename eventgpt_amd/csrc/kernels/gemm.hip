@@ -718,6 +718,7 @@ static bool use_256(int M, int N) {
 }
 
 static int g_forced_splitk = 0;
+static bool g_tail_splitk = true;
 
 // 768..1024 rows into a few thousand columns over a long contraction (one ~840-token sample against
 // the 4096-wide matrices with K = 11008 / 12288 / 22016): 48..128 tiles of 256x256 are a fraction of a
@@ -800,6 +801,34 @@ int gemm_splitk(int M, int N, int K) {
   return sk < 2 ? 1 : sk;
 }
 
+// One workgroup per CU means whole rounds of 256 tiles.  When the 8-wave kernel's last round would be
+// under half full (and there are only one or two full rounds for it to hide behind), the columns of the
+// whole rounds (n1) go first and the remaining ones are a second launch: on the 4-wave kernel, or --
+// *tail_s >= 2, contraction long enough -- on the 8-wave kernel again with K split tail_s ways so that
+// the few tiles spread over the idle CUs (4643 x 4096 x 11008: 304 tiles = 247 + 57 x 4 splits).
+static bool last_round_split(int M, int N, int K, int* n1, int* tail_s) {
+  const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+  const long long total = static_cast<long long>(tiles_m) * tiles_n;
+  const int rounds = static_cast<int>(total / 256), rem = static_cast<int>(total % 256);
+  const int cols1 = rounds >= 1 ? (rounds * 256) / tiles_m : 0;     // column tiles of the whole rounds
+  if (!(rounds >= 1 && rounds <= 2 && rem > 0 && rem < 128 && cols1 >= 1 && cols1 < tiles_n)) return false;
+  *n1 = cols1 * 256;
+  const int rem_tiles = tiles_m * (tiles_n - cols1);
+  int s = 256 / rem_tiles;
+  if (s > 4) s = 4;
+  *tail_s = (K >= 4096 && K % 64 == 0 && s >= 2 && g_tail_splitk) ? s : 0;
+  return true;
+}
+
+// fp32 workspace (floats) the last-round split of launch_gemm_bf16 wants for this shape, 0 if none
+long long gemm_tail_ws_floats(int M, int N, int K) {
+  if (g_forced_cfg >= 0 || g_forced_splitk > 0 || !use_256(M, N)) return 0;
+  int n1 = 0, s = 0;
+  if (!last_round_split(M, N, K, &n1, &s) || s < 2) return 0;
+  return static_cast<long long>(s) * M * (N - n1);
+}
+void gemm_enable_tail_splitk(bool on) { g_tail_splitk = on; }
+
 int gemm_argmax_partials(int M, int N) {
   switch (pick_cfg(M, N)) {  // tiles_n * WGN of the chosen config
     case CFG_256x256: return ((N + 255) / 256) * 4;
@@ -847,12 +876,8 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
   // to hide in), the 8-wave kernel takes the columns that make whole rounds and the 4-wave
   // kernel, several blocks per CU, the remaining ones.
   if (cfg == CFG_256x256 && g_forced_cfg < 0 && p.splitk == 1 && !amax_val) {
-    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
-    const long long total = static_cast<long long>(tiles_m) * tiles_n;
-    const int rounds = static_cast<int>(total / 256), rem = static_cast<int>(total % 256);
-    const int cols1 = rounds >= 1 ? (rounds * 256) / tiles_m : 0;     // column tiles of the whole rounds
-    if (rounds >= 1 && rounds <= 2 && rem > 0 && rem < 128 && cols1 >= 1 && cols1 < tiles_n) {
-      const int n1 = cols1 * 256;
+    int n1 = 0, tail_s = 0;
+    if (last_round_split(M, N, K, &n1, &tail_s)) {
       GemmParams a = p, b = p;
       a.N = n1;
       b.N = N - n1;
@@ -862,7 +887,20 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
       if (bias) b.bias = bias + n1;
       if (res) b.res = res + n1;
       launch_256<false, false>(a, st);
-      launch_cfg<128, 128, 2, 2, 2>(b, st);
+      if (tail_s >= 2 && splitk_ws) {
+        // the few tiles of the last round stay on the 8-wave kernel, their K split over the idle CUs
+        const int ksteps = K / 64;
+        b.k_per_split = ((ksteps + tail_s - 1) / tail_s) * 64;
+        b.splitk = (K + b.k_per_split - 1) / b.k_per_split;
+        b.partial = splitk_ws;
+        launch_256<false, false>(b, st);
+        const long long quads = (static_cast<long long>(b.M) * b.N + 3) / 4;
+        int blocks = static_cast<int>((quads + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, b);
+      } else {
+        launch_cfg<128, 128, 2, 2, 2>(b, st);
+      }
       return;
     }
   }

@@ -135,3 +135,32 @@ def test_linear_swiglu_epilogue(dev, M, I, K, cfg):
     want = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
     _check(fused, want, K)
     assert torch.allclose(fused.float(), plain.float(), atol=2e-2 * float(want.abs().max()), rtol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(4643, 4096, 4096), (4643, 4096, 11008), (5000, 4352, 4160)])
+def test_last_round_tiles_with_k_split(dev, M, N, K):
+    """Default dispatch of a shape whose 256 x 256 tiles are one full round plus a few: the few run the
+    8-wave kernel with K split over the idle CUs (fp32 slabs + reduce, bias / activation / residual applied
+    by the reduce).  Same result as with the split switched off (those columns on the 4-wave kernel) up to
+    the summation order, repeatable, and right against fp32."""
+    from eventgpt_amd.ops import hip
+    raw = hip.raw
+    x, w = _rand(M, K, dev=dev), _rand(N, K, dev=dev, seed=1, scale=0.05)
+    bias, res = _rand(N, dev=dev, seed=2), _rand(M, N, dev=dev, seed=3)
+    want = torch.nn.functional.gelu(x.float() @ w.float().t() + bias.float()).to(torch.bfloat16).float() + res.float()
+    try:
+        raw.gemm_enable_tail_splitk(True)
+        first = None
+        for _ in range(3):
+            y = raw.linear(x, w, bias, res, 1, False)
+            first = y if first is None else first
+            assert torch.equal(y, first)
+        raw.gemm_enable_tail_splitk(False)
+        off = raw.linear(x, w, bias, res, 1, False)
+    finally:
+        raw.gemm_enable_tail_splitk(True)
+    _check(first, want, K)
+    assert torch.allclose(first.float(), off.float(), atol=3e-2, rtol=2e-2)
+    # fp32 output path as well
+    yf = raw.linear(x, w, None, None, 0, True)
+    _check(yf, x.float() @ w.float().t(), K)
