@@ -945,6 +945,25 @@ void launch_gemm_glu(const bf16_t* A, const bf16_t* W, bf16_t* H, int M, int I, 
                nullptr, 0, K, K};
   p.glu_half = I;
   auto tiles = [&](int bm, int bn) { return static_cast<long long>((M + bm - 1) / bm) * ((2 * I + bn - 1) / bn); };
+  if (g_forced_cfg < 0 && use_256(M, 2 * I) && g_tail_splitk && I % 128 == 0) {
+    // a handful of 256 x 128 output tiles past the last full round (2115 rows x 11008: 774 = 3 x 256 + 6)
+    // would cost a whole further round of the 8-wave kernel: their columns go to 64 x 64 tiles instead
+    const int tiles_m = (M + 255) / 256, tiles_n = I / 128;
+    const long long total = static_cast<long long>(tiles_m) * tiles_n;
+    const int rounds = static_cast<int>(total / 256), rem = static_cast<int>(total % 256);
+    const int cols1 = rounds >= 1 ? (rounds * 256) / tiles_m : 0;
+    if (rounds >= 1 && rem > 0 && rem <= 48 && cols1 >= 1 && cols1 < tiles_n) {
+      const int n1 = cols1 * 128;
+      GemmParams a = p, b = p;
+      a.N = n1;
+      b.N = I - n1;
+      b.W = W + static_cast<size_t>(n1) * ldw;     // gate rows n1.., up rows glu_half + n1.. relative to it
+      b.C = H + n1;
+      launch_256<false, false>(a, st);
+      launch_cfg<64, 64, 2, 2, 4>(b, st);
+      return;
+    }
+  }
   if (g_forced_cfg == CFG_256x256 || (g_forced_cfg < 0 && use_256(M, 2 * I))) launch_256<false, false>(p, st);
   else if (g_forced_cfg == CFG_128x128 || (g_forced_cfg < 0 && tiles(128, 128) >= 384)) launch_cfg<128, 128, 2, 2, 2>(p, st);
   else if (g_forced_cfg == CFG_64x64) launch_cfg<64, 64, 2, 2, 4>(p, st);

@@ -164,3 +164,25 @@ def test_last_round_tiles_with_k_split(dev, M, N, K):
     # fp32 output path as well
     yf = raw.linear(x, w, None, None, 0, True)
     _check(yf, x.float() @ w.float().t(), K)
+
+
+@pytest.mark.parametrize("M,I,K", [(2115, 4096, 1024), (1500, 11008, 512), (2115, 11008, 4096)])
+def test_swiglu_gemm_last_tiles_on_small_tiles(dev, M, I, K):
+    """The gate/up GEMM with the SwiGLU epilogue when its 256 x 128 output tiles are whole rounds plus a
+    handful: those columns run 64 x 64 tiles (a second launch over a column range of the packed
+    [gate | up] matrix).  Same result as the single launch, right against fp32."""
+    from eventgpt_amd.ops import hip
+    raw = hip.raw
+    x, w = _rand(M, K, dev=dev), _rand(2 * I, K, dev=dev, seed=1, scale=0.05)
+    gu = x.float() @ w.float().t()
+    want = torch.nn.functional.silu(gu[:, :I].to(torch.bfloat16).float()) * gu[:, I:].to(torch.bfloat16).float()
+    try:
+        raw.gemm_enable_tail_splitk(True)
+        y = raw.linear_swiglu(x, w)
+        assert torch.equal(y, raw.linear_swiglu(x, w))
+        raw.gemm_enable_tail_splitk(False)
+        one = raw.linear_swiglu(x, w)
+    finally:
+        raw.gemm_enable_tail_splitk(True)
+    _check(y, want, K)
+    assert torch.allclose(y.float(), one.float(), atol=2e-2, rtol=2e-2)
