@@ -772,7 +772,23 @@ int gemm_splitk(int M, int N, int K) {
   // measured (benchmarks/bench_gemm.py): the extra reduce pass only pays for
   // weight-streaming shapes with a handful of rows (batched decode, verify)
   if (M > 32) {
-    if (M > 1024) return 1;
+    if (M > 1024) {
+      // A single partial round of 256 x 256 tiles over a long contraction: with K split s ways the tiles
+      // make ceil(t s / 256) rounds of 1 / s the length.  Taken when that model promises a third off and
+      // s <= 3 (the fp32 slabs cost about one more pass over the output per split): 2115 x 4096 x 11008,
+      // 144 tiles, s = 3: 231-262 -> 209 us; 1500 rows, 96 tiles, s = 2: 152 -> 130 us; 2885 rows, 192
+      // tiles: every split count measures behind and the model agrees.
+      if (g_tail_splitk && K >= 8192 && use_256(M, N)) {
+        const long long t = static_cast<long long>((M + 255) / 256) * ((N + 255) / 256);
+        if (t < 256) {
+          for (int s = 2; s <= 3; ++s) {
+            const long long rounds = (t * s + 255) / 256;
+            if (3 * rounds <= 2 * s) return s;     // rounds / s <= 2 / 3
+          }
+        }
+      }
+      return 1;
+    }
     if (!use_256(M, N) && narrow_256_splits(M, N, K) >= 2) return narrow_256_splits(M, N, K);
     const GemmCfg cfg = pick_cfg(M, N, K);
     const long long tl = cfg_tiles(cfg, M, N);

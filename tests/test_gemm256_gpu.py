@@ -137,7 +137,8 @@ def test_linear_swiglu_epilogue(dev, M, I, K, cfg):
     assert torch.allclose(fused.float(), plain.float(), atol=2e-2 * float(want.abs().max()), rtol=2e-2)
 
 
-@pytest.mark.parametrize("M,N,K", [(4643, 4096, 4096), (4643, 4096, 11008), (4000, 4608, 4160)])
+@pytest.mark.parametrize("M,N,K", [(4643, 4096, 4096), (4643, 4096, 11008), (4000, 4608, 4160),
+                                   (2115, 4096, 11008), (1500, 4096, 8192)])   # the last two: one partial round, all tiles split
 def test_last_round_tiles_with_k_split(dev, M, N, K):
     """Default dispatch of a shape whose 256 x 256 tiles are one full round plus a few: the few run the
     8-wave kernel with K split over the idle CUs (fp32 slabs + reduce, bias / activation / residual applied
