@@ -48,7 +48,10 @@ def test_single_gpu_default_does_not_launch():
     sys.path.insert(0, ROOT)
     import bench
     a = bench.parse_args([])
-    assert a.gpus == 1 and a.parallelism == "tp" and a.batch == 1
+    assert a.gpus == 1 and a.parallelism == "tp" and a.batch == 1 and a.settle_steps == 96
+    child = bench.oneshot_child_command(bench.parse_args(["--gpus", "4", "--steps", "20", "--settle-steps", "50"]), 4)
+    assert child[child.index("--allreduce") + 1] == "auto" and child[child.index("--settle-steps") + 1] == "50"
+    assert "--no-oneshot-extra" in child and "--no-dp-extra" in child      # the child job does not nest another
     cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "5"], 29999)
     assert "--nproc-per-node=8" in cmd and cmd[-4:] == ["--gpus", "8", "--steps", "5"]
     assert "127.0.0.1" in cmd
