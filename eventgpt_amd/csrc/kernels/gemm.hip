@@ -806,11 +806,16 @@ int gemm_splitk(int M, int N, int K) {
     return s < 1 ? 1 : (s > 4 ? 4 : s);
   }
   const long long t = cfg_tiles(pick_cfg(M, N), M, N);
-  if (t >= 256) return 1;
-  // one block per CU.  Twice as many splits stream the weights 5-20 % faster in
-  // isolation (6 rows: qkv 4.4 -> 5.3 TB/s), but the consumer then sums twice as
-  // many slabs and a whole verify pass / batched decode step comes out 2-3 % slower.
+  if (t >= 512) return 1;
+  // At least one block per CU, and at least four splits while the tiles are fewer than two per CU
+  // (the 7B decoder's qkv and gate/up: 192 and 344 tiles of 32 x 64): batched decode steps with every
+  // projection split four ways against one block per CU (qkv 2, gate/up unsplit), ms per step on one box:
+  // 8 streams 4.08 -> 3.84, 16 streams 4.61 -> 4.39, 32 streams 5.75 -> 5.50-5.58.  More than that loses
+  // again (six or eight splits everywhere: 6.1-6.2 at 32 streams): the consumers sum every slab, and
+  // their all-loads-first path exists for 1, 2, 4 and 8 slabs only (three or six for one projection:
+  // 5.68-5.77 against 5.66 at 32 streams, 3.86-3.93 against 3.80 ms per verify pass of five drafts).
   int sk = static_cast<int>((256 + t - 1) / t);
+  if (sk < 4) sk = 4;
   const int max_by_k = (K / 64) / 8;
   if (sk > max_by_k) sk = max_by_k;
   if (sk > 16) sk = 16;
