@@ -1,6 +1,7 @@
 """Where one instruction-tuning step goes (7B geometry, random weights, synthetic data):
 ``python benchmarks/bench_sft_step.py [projector|lora|full] [n_steps]`` prints the mean
-host-preparation, forward, backward and optimizer times."""
+host-preparation, forward, backward and optimizer times, and how long the host needed to issue
+the forward and the backward (close to the phase's own time = the GPU waits for the host)."""
 import sys
 import tempfile
 import time
@@ -25,6 +26,7 @@ ds = InstructionDataset(make_synthetic_dataset(tempfile.mkdtemp(prefix="evgpt_sf
 tr = SFTTrainer(model, tok, ds, info, tune=tune, output_dir=tempfile.mkdtemp(prefix="evgpt_sftb_out_"))
 model.train()
 acc = {"prepare": 0.0, "forward": 0.0, "backward": 0.0, "optimizer": 0.0}
+issue = {"forward": 0.0, "backward": 0.0}
 
 
 def tick():
@@ -37,8 +39,10 @@ for i in range(steps + 3):
     prep = tr.prepare_sample(ds[i])
     t1 = tick()
     loss = tr.sample_loss(ds[i], prep)
+    e1 = time.perf_counter()
     t2 = tick()
     loss.backward()
+    e2 = time.perf_counter()
     t3 = tick()
     tr.opt.step(max_grad_norm=1.0)
     tr.opt.zero_grad()
@@ -46,6 +50,8 @@ for i in range(steps + 3):
     if i >= 3:
         for k, v in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
             acc[k] += v
+        issue["forward"] += e1 - t1
+        issue["backward"] += e2 - t2
 tokens = int(prep["ids"].shape[0]) + 5 + 576
 print(tune, {k: round(v / steps * 1e3, 2) for k, v in acc.items()}, "ms per step; ~%d tokens per sample" % tokens,
-      flush=True)
+      "; host issue", {k: round(v / steps * 1e3, 2) for k, v in issue.items()}, flush=True)
