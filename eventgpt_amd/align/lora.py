@@ -70,7 +70,12 @@ class LoRALinear(nn.Module):
         base projection itself (several wrapped layers grouped into one GEMM); None once merged."""
         if self.merged:
             return None
-        return self.lora_B(self.lora_A(self.lora_dropout(x)) * self.scaling)
+        return self._low(x)
+
+    def _low(self, x):
+        # the scale rides on the rank-r intermediate ([rows, r]), not on the [rows, out] product
+        from ..ops import lowrank_delta
+        return lowrank_delta(self.lora_dropout(x), self.lora_A.weight, self.lora_B.weight, self.scaling)
 
     def forward(self, x, act: Optional[str] = None, residual=None):
         plain = type(self.base) is nn.Linear
@@ -81,8 +86,7 @@ class LoRALinear(nn.Module):
             return self.base(x, act=act, residual=residual)
         if act:
             raise NotImplementedError("LoRA on a layer with a fused activation is not supported")
-        # the scale rides on the rank-r intermediate ([rows, r]), not on the [rows, out] product
-        low = self.lora_B(self.lora_A(self.lora_dropout(x)) * self.scaling)
+        low = self._low(x)
         extra = low if residual is None else low + residual
         # the low-rank update rides on the base GEMM's residual epilogue
         return self.base(x) + extra if plain else self.base(x, residual=extra)

@@ -200,6 +200,21 @@ Tensor linear_t(const Tensor& a, const Tensor& w, bool a_t, bool w_t, const c10:
   return y;
 }
 
+// t [.., R] = alpha * x [.., K] · w [R, K]^T for a low-rank adapter's R <= 16 rows: one launch, no split-K pass
+Tensor lowrank_out(const Tensor& x, const Tensor& w, double alpha) {
+  check_bf16(x, "x"); check_bf16(w, "w");
+  TORCH_CHECK(w.dim() == 2 && x.dim() >= 1, "lowrank_out: w is [R, K]");
+  const int64_t K = x.size(-1), R = w.size(0), M = K ? x.numel() / K : 0;
+  TORCH_CHECK(w.size(1) == K && K % 8 == 0 && K >= 8, "lowrank_out: K mismatch or K % 8 != 0");
+  TORCH_CHECK(R >= 1 && R <= 16, "lowrank_out: 1 <= R <= 16");
+  TORCH_CHECK(M < (1ll << 31) / 16 && x.numel() < (1ll << 40), "lowrank_out: too many rows");
+  auto sizes = x.sizes().vec();
+  sizes.back() = R;
+  Tensor y = at::empty(sizes, x.options());
+  if (M > 0) evgpt::launch_lowrank_out(bptr(x), bptr(w), bptr_mut(y), (int)M, (int)R, (int)K, (float)alpha, cur_stream());
+  return y;
+}
+
 // ---- few-row projections: GEMM to fp32 split-K slabs + a fused consumer ----
 // partial [nslab, M, N] fp32 (nslab >= 1); the consumers below sum the slabs.
 Tensor linear_partial(const Tensor& x, const Tensor& w) {
@@ -1076,6 +1091,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("linear(Tensor x, Tensor w, Tensor? bias, Tensor? res, int act, bool out_f32) -> Tensor", &linear);
   m.def("linear_swiglu(Tensor x, Tensor w_gate_up) -> Tensor", &linear_swiglu);
   m.def("linear_partial(Tensor x, Tensor w) -> Tensor", &linear_partial);
+  m.def("lowrank_out(Tensor x, Tensor w, float alpha) -> Tensor", &lowrank_out);
   m.def("linear_t(Tensor a, Tensor w, bool a_t, bool w_t, Tensor? bias, Tensor? res, int act, bool out_f32, int K, Tensor(a!)? out=None) -> Tensor", &linear_t);
   m.def("gemv_max_batch() -> int", []() -> int64_t { return evgpt::gemv_max_batch(); });
   m.def("reduce_residual_norm(Tensor partial, Tensor? res, Tensor? norm_w, float eps, Tensor(a!)? out) -> (Tensor, Tensor)", &reduce_residual_norm);

@@ -93,6 +93,16 @@ def apply_rope(x, positions, cos, sin):
     return ref.apply_rope(x, positions, cos, sin)
 
 
+def lowrank_delta(x, a, b, scale: float):
+    """``(scale * x A^T) B^T`` with A ``[r, K]`` and B ``[N, r]``: a low-rank adapter's update."""
+    if _use_hip(x, a, b) and x.dtype == a.dtype == b.dtype == torch.bfloat16 and a.shape[0] <= 16 \
+            and a.shape[1] % 8 == 0 and a.is_contiguous() and x.numel() > 0:
+        return _hip().linear(_hip().raw.lowrank_out(x.contiguous(), a, float(scale)), b)
+    if _train(x, a, b):
+        return _diff().lowrank_delta(x, a, b, scale)
+    return linear(linear(x, a) * scale, b)
+
+
 def add_column_blocks(y, blocks, widths):
     """``y[..., off_i : off_i + widths[i]] += blocks[i]`` for the blocks that are not None; ``y`` is a
     freshly computed tensor (updated in place).  Returns ``y``."""

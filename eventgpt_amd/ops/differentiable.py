@@ -222,6 +222,16 @@ def _transposed_for_dgrad(weight) -> Optional[torch.Tensor]:
     return wt
 
 
+def _wgrad_to_sink(weight, g2, x2):
+    """``dW = g2^T x2``, written into the parameter's published gradient slot if that is still free."""
+    sink = getattr(weight, "_grad_sink", None)
+    if (sink is not None and weight.grad is None and not getattr(weight, "_grad_sink_used", True)
+            and sink.dtype == g2.dtype and sink.shape == weight.shape and sink.is_contiguous()):
+        weight._grad_sink_used = True
+        return linear_wgrad(g2, x2, out=sink).view_as(weight)
+    return linear_wgrad(g2, x2)
+
+
 class _Linear(torch.autograd.Function):
     """``y = x @ W^T + b`` on the in-tree MFMA GEMM, forward and both backward products."""
 
@@ -257,13 +267,7 @@ class _Linear(torch.autograd.Function):
             # A weight used several times in one graph gets all its gradients summed by autograd
             # BEFORE ``.grad`` is set, so "the slot is free" is tracked by the optimizer's own flag
             # (cleared by its ``zero_grad``), never inferred from ``.grad`` alone.
-            sink = getattr(weight, "_grad_sink", None)
-            if (sink is not None and weight.grad is None and not getattr(weight, "_grad_sink_used", True)
-                    and sink.dtype == g2.dtype and sink.shape == weight.shape and sink.is_contiguous()):
-                weight._grad_sink_used = True
-                dw = linear_wgrad(g2, x2, out=sink).view_as(weight)
-            else:
-                dw = linear_wgrad(g2, x2)
+            dw = _wgrad_to_sink(weight, g2, x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = g2.float().sum(0).to(gy.dtype)
         return dx, dw, db
@@ -284,6 +288,46 @@ def linear(x, weight, bias=None, act: Optional[str] = None, residual=None):
         y = F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
     y = _ACTS[act](y)
     return y if residual is None else y + residual
+
+
+class _LowRank(torch.autograd.Function):
+    """``(scale * x A^T) B^T`` of a low-rank adapter (A ``[r, K]``, B ``[N, r]``, r <= 16).  The two
+    products with an r-wide OUTPUT -- ``x A^T`` forward, ``dY B`` backward -- run the rank-r kernel (one
+    launch each, the scale applied to its fp32 sums) instead of a tiled GEMM with a K split and its
+    reduction pass; the wide ones (``t B^T``, ``dt A`` and both weight gradients) stay on the GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, a, b, scale):
+        from . import hip
+        xc = x if x.is_contiguous() else x.contiguous()
+        t = _raw().lowrank_out(xc, a, scale)                       # [.., r]
+        ctx.save_for_backward(xc.view(-1, xc.shape[-1]), t.view(-1, t.shape[-1]), a, b)
+        ctx.scale = scale
+        return hip.linear(t, b)                                    # [.., N], the kernel's own output
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, t2, a, b = ctx.saved_tensors
+        g2 = gy.reshape(-1, b.shape[0])
+        g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        dx = da = db = None
+        dt = _raw().lowrank_out(g2, b.detach().t().contiguous(), ctx.scale)      # scale * dY B  [M, r]
+        if ctx.needs_input_grad[2]:
+            db = _wgrad_to_sink(b, g2, t2)
+        if ctx.needs_input_grad[1]:
+            da = _wgrad_to_sink(a, dt, x2)
+        if ctx.needs_input_grad[0]:
+            dx = linear_dgrad(dt, a.detach().contiguous()).view(*gy.shape[:-1], a.shape[1])
+        return dx, da, db, None
+
+
+def lowrank_delta(x, a, b, scale: float):
+    """``(scale * x A^T) B^T``: the update a low-rank adapter adds to its layer's output."""
+    r, k = a.shape
+    if (_fused(x, a, b) and x.numel() > 0 and r <= 16 and r % 8 == 0 and k % 8 == 0 and b.shape[0] % 8 == 0
+            and x.shape[-1] == k and b.shape[1] == r and a.is_contiguous() and b.is_contiguous()):
+        return _LowRank.apply(x, a, b, float(scale))
+    return linear(linear(x, a) * scale, b)
 
 
 def swiglu(gate_up):

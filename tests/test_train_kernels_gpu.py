@@ -129,6 +129,46 @@ def test_frozen_weight_dgrad_through_transposed_copy(dev):
     assert release_transposed_dgrad(mod) == spent and not hasattr(lin.weight, "_dgrad_t")
 
 
+@pytest.mark.parametrize("M,R,K", [(836, 16, 4096), (5, 16, 4096), (16, 8, 4096), (17, 16, 1376), (1030, 16, 11008),
+                                   (33, 3, 72), (836, 16, 8)])
+def test_rank_r_projection_matches_fp32(dev, M, R, K):
+    """alpha * X W^T for R <= 16 output columns: rows past M, W rows past R and K-steps past K are
+    staged as zeros (every element is non-zero, so a chunk taken from a neighbour shows)."""
+    from eventgpt_amd.ops import hip
+    x = _rand(M, K, dev=dev) + 0.25
+    w = _rand(R, K, dev=dev, seed=1, scale=0.1) + 0.125
+    y = hip.raw.lowrank_out(x, w, 2.0)
+    assert y.shape == (M, R) and y.dtype == torch.bfloat16
+    _close(y, 2.0 * (x.float() @ w.float().t()), 3e-2 * math.sqrt(K / 64 + 1), 2e-2)
+    y3 = hip.raw.lowrank_out(x.view(1, M, K), w, 2.0)
+    assert y3.shape == (1, M, R) and torch.equal(y3.view(M, R), y)
+
+
+@pytest.mark.parametrize("M", [836, 6])
+def test_low_rank_update_gradients(dev, M):
+    """(s x A^T) B^T as one autograd node: output and the three gradients against an fp32 computation
+    with the same two bf16 intermediates (t = s x A^T forward, dt = s dY B backward)."""
+    from eventgpt_amd import ops
+    K, N, r, s = 4096, 4096, 16, 2.0
+    x = _rand(1, M, K, dev=dev).requires_grad_(True)
+    a = _rand(r, K, dev=dev, seed=1, scale=0.02).requires_grad_(True)
+    b = _rand(N, r, dev=dev, seed=2, scale=0.05).requires_grad_(True)
+    go = _rand(1, M, N, dev=dev, seed=3)
+    y = ops.lowrank_delta(x, a, b, s)
+    assert type(y.grad_fn).__name__ == "_LowRankBackward"
+    y.backward(go)
+    xf, af, bf, gf = (t.detach().float().view(-1, t.shape[-1]) for t in (x, a, b, go))
+    t = (s * (xf @ af.t())).bfloat16().float()
+    dt = (s * (gf @ bf)).bfloat16().float()
+    yf = t @ bf.t()
+    _close(y.view(M, N), yf, 2e-2, 2e-2)
+    _close(x.grad.view(M, K), dt @ af, 2e-2, 2e-2)
+    _close(a.grad, dt.t() @ xf, 2e-2 * math.sqrt(M / 16), 2e-2)
+    _close(b.grad, gf.t() @ t, 2e-2 * math.sqrt(M / 16), 2e-2)
+    with torch.no_grad():      # inference takes the same two kernels
+        _close(ops.lowrank_delta(x.detach(), a.detach(), b.detach(), s).view(M, N), yf, 2e-2, 2e-2)
+
+
 def _attn_ref_grads(q, k, v, go, causal, q_offset):
     qf, kf, vf = (t.detach().float().requires_grad_(True) for t in (q, k, v))
     rep = q.shape[2] // k.shape[2]          # grouped KV heads: the oracle takes them expanded
