@@ -271,3 +271,31 @@ def test_group_frozen_weights_is_a_gpu_feature():
     assert group_frozen_weights((mlp.gate_proj, mlp.up_proj)) is None and not mlp.group_frozen()
     x = torch.randn(2, 5, 64)
     assert mlp(x).shape == (2, 5, 64)
+
+
+def test_low_rank_update_on_cpu_and_through_the_lora_wrapper():
+    """``ops.lowrank_delta`` has a plain-tensor fallback ((s x A^T) B^T with autograd's own gradients),
+    and a wrapped layer's output is its base plus that update (dropout off)."""
+    import torch
+    from eventgpt_amd import ops
+    from eventgpt_amd.align.lora import LoRALinear
+    torch.manual_seed(0)
+    x = torch.randn(2, 5, 32, requires_grad=True)
+    a = torch.randn(8, 32, requires_grad=True)
+    b = torch.randn(24, 8, requires_grad=True)
+    y = ops.lowrank_delta(x, a, b, 0.5)
+    ref = ((x @ a.t()) * 0.5) @ b.t()
+    assert torch.allclose(y, ref, atol=1e-5)
+    g = torch.randn_like(y)
+    got = torch.autograd.grad(y, (x, a, b), g)
+    want = torch.autograd.grad(ref, (x, a, b), g)
+    for u, v in zip(got, want):
+        assert torch.allclose(u, v, atol=1e-5)
+    lin = LoRALinear(torch.nn.Linear(32, 24), r=8, alpha=16, dropout=0.0)
+    torch.nn.init.normal_(lin.lora_B.weight)
+    xs = torch.randn(3, 32)
+    want = lin.base(xs) + ((xs @ lin.lora_A.weight.t()) * 2.0) @ lin.lora_B.weight.t()
+    assert torch.allclose(lin(xs), want, atol=1e-5)
+    assert torch.allclose(lin.lora_delta(xs), want - lin.base(xs), atol=1e-5)
+    lin.merge()
+    assert lin.lora_delta(xs) is None and torch.allclose(lin(xs), want, atol=1e-4)
