@@ -24,9 +24,13 @@ The timed region is exactly the K steps after the W warm-up steps, bracketed by 
   scaling, every decode step crosses 64 all-reduces -- and ``value`` is its tokens/s.  The
   batched configuration (32 event streams on the same TP group) is measured in the same run
   and reported under ``tp_batch32``, and so are N independent replicas (``dp_replicas``: no
-  communication in the step, the fabric-free bound) and, up to 4 ranks, the same tensor-parallel
-  measurement on the in-tree one-shot / two-shot all-reduce (``tp_oneshot``: run as a child job of
-  every rank on its own process group, because that collective has never crossed a real link).
+  communication in the step, the fabric-free bound), one data-parallel fine-tuning step of the 7B
+  model through the sharded AdamW's reduce-scatter / all-gather (``dp_train``: projector and LoRA
+  stage), prefill hiding with drafter and verifier on two GPUs (``sd_two_gpu``) and, last, the same
+  tensor-parallel measurement on the in-tree one-shot / two-shot all-reduce (``tp_oneshot``: run as
+  a child job of every rank on its own process group, at any width up to 8, because that collective
+  has never crossed a real link; before it starts, the line as it stands is also written to stderr
+  and to ``gpurun_out/bench_line_before_oneshot.json``).
   The extras share a time limit (``--extras-timeout``) after which the line is printed without them.  ``--parallelism dp`` (independent replicas, no
   communication in the step) is available but is never the default: its curve says nothing
   about the fabric.
@@ -82,8 +86,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-oneshot-extra", action="store_true",
                     help="multi-GPU tp runs over RCCL: skip the additional run on the in-tree one-shot / two-shot "
                          "all-reduce (a child job per rank, so that nothing it does can cost the headline line)")
-    ap.add_argument("--oneshot-extra-timeout", type=float, default=240.0, help="seconds the child job may take")
-    ap.add_argument("--extras-timeout", type=float, default=540.0,
+    ap.add_argument("--oneshot-extra-timeout", type=float, default=200.0, help="seconds the child job may take")
+    ap.add_argument("--no-dp-train-extra", action="store_true",
+                    help="multi-GPU tp runs: skip the data-parallel fine-tuning step (sharded AdamW over the group)")
+    ap.add_argument("--no-sd-extra", action="store_true",
+                    help="multi-GPU tp runs: skip prefill hiding with drafter and verifier on two GPUs")
+    ap.add_argument("--extras-timeout", type=float, default=420.0,
                     help="multi-GPU tp runs: seconds the additional measurements may take after the headline one; "
                          "past it the line is printed without them and the process ends (0 = no limit)")
     ap.add_argument("--extras-stall", type=float, default=0.0, help=argparse.SUPPRESS)  # tests of the limit: idle first
@@ -144,6 +152,20 @@ def probe_main(args) -> None:
         dist.destroy_process_group()
 
 
+_CHILDREN = []      # child jobs of this rank that may still run
+
+
+def kill_children() -> None:
+    """End every child job of this rank, its whole process group (the child is a session leader)."""
+    import signal
+    for proc in list(_CHILDREN):
+        if proc.poll() is None:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+
+
 def oneshot_child_command(args, world: int):
     """This script again, as one rank of a second job of the same size whose tensor-parallel engine
     asks for the in-tree all-reduce (``auto``: taken if its self-test passes, RCCL otherwise)."""
@@ -152,7 +174,9 @@ def oneshot_child_command(args, world: int):
            "--max-len", str(args.max_len), "--model", args.model,
            # (a gloo group only bootstraps the exchange of handles: there the mode is asked for outright)
            "--allreduce", "oneshot" if args.rehearsal else "auto",
-           "--no-dp-extra", "--no-oneshot-extra", "--extras-timeout", "120",
+           "--no-dp-extra", "--no-oneshot-extra", "--no-dp-train-extra", "--no-sd-extra",
+           # its only extra is the 32-stream run: a 7B build + engine + run fits well inside this
+           "--extras-timeout", str(max(60, int(args.oneshot_extra_timeout * 0.6))),
            "--settle-steps", str(args.settle_steps)]
     if args.rehearsal:
         cmd.append("--rehearsal")
@@ -176,13 +200,27 @@ def run_oneshot_child(args, dist, rank: int, world: int, local_rank: int, dev):
     env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(int(port.item())), "RANK": str(rank),
                 "WORLD_SIZE": str(world), "LOCAL_RANK": str(local_rank), "LOCAL_WORLD_SIZE": str(world),
                 "EVGPT_BENCH_CHILD": "1"})
-    r = subprocess.run(oneshot_child_command(args, world), env=env, capture_output=True, text=True,
-                       timeout=args.oneshot_extra_timeout)
+    # its own session: on a time-out -- here or in the extras' watchdog -- the whole group of the child is
+    # killed, so nothing of it keeps holding a GPU after this process has gone
+    proc = subprocess.Popen(oneshot_child_command(args, world), env=env, stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, text=True, start_new_session=True)
+    _CHILDREN.append(proc)
+    try:
+        stdout, stderr = proc.communicate(timeout=args.oneshot_extra_timeout)
+    except subprocess.TimeoutExpired:
+        kill_children()
+        stdout, stderr = proc.communicate()
+        if rank != 0:
+            return None
+        return {"error": f"child job not finished within {args.oneshot_extra_timeout} s"}
+    finally:
+        if proc in _CHILDREN and proc.poll() is not None:
+            _CHILDREN.remove(proc)
     if rank != 0:
         return None
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    if r.returncode != 0 or not lines:
-        return {"error": f"child job ended with status {r.returncode}: {r.stderr.strip()[-160:]}"}
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        return {"error": f"child job ended with status {proc.returncode}: {stderr.strip()[-160:]}"}
     got = json.loads(lines[-1])
     out = {"tokens_per_s": got["value"], "ms_per_step": got["ms_per_step"], "tp_allreduce": got["tp_allreduce"],
            "graph_captured": got["graph_captured"], "event_prefill_ms": got["event_prefill_ms"]}
@@ -249,9 +287,19 @@ def timed_decode(args, engine, embeds, batch: int, dist, dev):
     # from then on (`benchmarks/bench_decode_steps.py`).  A serving engine lives in the second state, and the
     # reference's figure is an average over whole generations, so the sequence is decoded once for
     # ``--settle-steps`` steps, then started again for the W warm-up steps and the K timed ones.
+    cold_ms = None
     if args.settle_steps > 0:
         start()
-        for _ in range(args.settle_steps):
+        # the unsettled figure, for the record: the first steps after the prefill, as a run without the
+        # settling phase would time them (they are the start of that phase, not additional work)
+        n_cold = min(20, args.settle_steps)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(n_cold):
+            engine.decode_step(True)
+        sync_all()
+        cold_ms = (time.perf_counter() - t0) * 1e3 / n_cold
+        for _ in range(args.settle_steps - n_cold):
             engine.decode_step(True)
     start()
     for _ in range(args.warmup):
@@ -267,8 +315,9 @@ def timed_decode(args, engine, embeds, batch: int, dist, dev):
         t = torch.tensor([dt], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if getattr(engine, "oneshot", None) is not None:
-        engine.oneshot.check()          # a timed-out device wait must fail the run, not colour it
+    if hasattr(engine, "check_collectives"):
+        engine.check_collectives()      # a timed-out device wait (one-shot or two-shot) must fail the run, not colour it
+    timed_decode.cold_ms = cold_ms
     return dt
 
 
@@ -357,6 +406,7 @@ def main(argv=None):
 
     # ---- decode
     dt = timed_decode(args, engine, embeds, args.batch, dist, dev)
+    cold_ms = timed_decode.cold_ms
     streams = (1 if tp else world) * args.batch
     tok_s = streams * args.steps / dt
     graph_captured = bool(engine.graph_captured)
@@ -366,16 +416,14 @@ def main(argv=None):
     extra = {}
     printed = threading.Lock()
 
-    def emit() -> None:
-        """Rank 0's one JSON line; whichever of the normal end and the extras' time limit comes first."""
-        if rank != 0 or not printed.acquire(blocking=False):
-            return
-        print(json.dumps({
+    def line() -> dict:
+        return {
             "metric": "decode tokens/sec (EventGPT-7B bf16 greedy, bs 1 per stream)" if args.batch == 1
             else f"decode tokens/sec (EventGPT-7B bf16 greedy, {args.batch} streams per engine)",
             "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "settle_steps": args.settle_steps,
             "ms_per_step": round(dt * 1e3 / args.steps, 4),
+            **({} if cold_ms is None else {"ms_per_step_cold": round(cold_ms, 4)}),
             "higher_is_better": True,
             "scaling": "strong" if (tp or world == 1) else "weak",
             "vs_baseline": round(tok_s / BASELINE_DECODE_TOK_S, 3),
@@ -392,20 +440,36 @@ def main(argv=None):
             "config": {"model": model_name, "global_batch": streams, "seq_len": S,
                        "event_frames": args.frames,
                        "parallelism": f"{args.parallelism}{world}"},
-        }), flush=True)
+        }
+
+    def emit() -> None:
+        """Rank 0's one JSON line; whichever of the normal end and the extras' time limit comes first."""
+        if rank != 0 or not printed.acquire(blocking=False):
+            return
+        print(json.dumps(line()), flush=True)
 
     # ---- extras (never the value).  They run after the headline measurement and must not be able
     # to cost it: an exception is reported under the extra's key (every rank takes the same
     # branch, so the group stays in step), and if the extras as a whole outlast their time limit
     # -- ranks waiting in a collective that one of them has left -- every rank prints what it
-    # has and ends the process.
-    want_oneshot = (tp and args.batch == 1 and not args.no_oneshot_extra and world <= 4
-                    and tp_allreduce in ("rccl", "gloo"))
-    want_extras = tp and args.batch == 1 and not (args.no_batch32 and args.no_dp_extra and not want_oneshot)
-    if want_extras and args.extras_timeout > 0:
+    # has, ends its child job and ends the process.
+    multi = tp and args.batch == 1
+    plan = []
+    if multi and not args.no_batch32:
+        plan.append("tp_batch32")
+    if multi and not args.no_dp_extra:
+        plan.append("dp_replicas")
+    if multi and not args.no_dp_train_extra:
+        plan.append("dp_train")
+    if multi and not args.no_sd_extra:
+        plan.append("sd_two_gpu")
+    if multi and not args.no_oneshot_extra and tp_allreduce in ("rccl", "gloo"):
+        plan.append("tp_oneshot")          # last: the one extra whose code has never run on this fabric
+    if plan and args.extras_timeout > 0:
         def give_up():
-            for name in ("tp_batch32", "dp_replicas") + (("tp_oneshot",) if want_oneshot else ()):
+            for name in plan:
                 extra.setdefault(name, {"error": f"not finished within {args.extras_timeout} s"})
+            kill_children()
             emit()
             sys.stdout.flush()
             os._exit(0)
@@ -417,10 +481,18 @@ def main(argv=None):
     if args.extras_stall > 0:
         torch.cuda.synchronize()
         time.sleep(args.extras_stall)
-    # the batched TP configuration (32 event streams), same group, same run
-    if tp and args.batch == 1 and not args.no_batch32:
+
+    def free_headline_engine():
+        nonlocal engine, model
+        if engine is not None and hasattr(engine, "close"):
+            engine.close()                 # peer mappings go in an order all ranks agree on
         engine = model = None
         torch.cuda.empty_cache()
+
+    # the batched TP configuration (32 event streams), same group, same run
+    if "tp_batch32" in plan:
+        free_headline_engine()
+        eng32 = model32 = None
         try:
             _, model32, _ = build_model(args, dev)
             eng32 = build_engine(args, model32, dist, True, 32)
@@ -431,12 +503,16 @@ def main(argv=None):
                                    "tp_allreduce": getattr(eng32, "allreduce_kind", "none")}
         except Exception as e:
             extra["tp_batch32"] = {"error": str(e)[:200]}
+        try:
+            if eng32 is not None:
+                eng32.close()
+        except Exception:
+            pass
         eng32 = model32 = None
     # independent replicas on the same GPUs (no communication in the step): the fabric-free
     # bound the tensor-parallel numbers can be read against
-    if tp and args.batch == 1 and not args.no_dp_extra:
-        engine = model = None
-        torch.cuda.empty_cache()
+    if "dp_replicas" in plan:
+        free_headline_engine()
         try:
             _, model_dp, _ = build_model(args, dev)
             eng_dp = build_engine(args, model_dp, None, False, 1)
@@ -447,11 +523,48 @@ def main(argv=None):
         except Exception as e:
             extra["dp_replicas"] = {"error": str(e)[:200]}
         eng_dp = model_dp = None
-    # the same tensor-parallel measurement on the in-tree all-reduce, as a child job (at most 4 ranks:
-    # parents and children together stay well inside a node's limit on processes that hold a GPU)
-    if want_oneshot:
-        engine = model = None
+    # one fine-tuning step per rank through the sharded AdamW's reduce-scatter / all-gather
+    if "dp_train" in plan:
+        free_headline_engine()
+        try:
+            from eventgpt_amd.benchmarks.multi_gpu_extras import dp_train_extra
+            extra["dp_train"] = dp_train_extra(args.model, dist, dev, world, rank,
+                                               steps=min(max(args.steps // 4, 2), 8), warmup=2)
+        except Exception as e:
+            extra["dp_train"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         torch.cuda.empty_cache()
+    # prefill hiding with the verifier on rank 1's GPU (rank 0 drives both devices, the others wait)
+    if "sd_two_gpu" in plan:
+        free_headline_engine()
+        on_host = dist.get_backend() == "gloo"
+        try:
+            if rank == 0:
+                from eventgpt_amd.benchmarks.multi_gpu_extras import sd_two_gpu_extra
+                dev1 = dev if (args.rehearsal or torch.cuda.device_count() < 2) else torch.device("cuda", 1)
+                short = args.model != "7b"
+                extra["sd_two_gpu"] = sd_two_gpu_extra(args.model, dev, dev1, new_tokens=24 if short else 50,
+                                                       drafter_prompt=120 if short else 636,
+                                                       verifier_prompt=400 if short else 2115)
+        except Exception as e:
+            extra["sd_two_gpu"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        torch.cuda.set_device(dev)
+        torch.cuda.empty_cache()
+        flag = torch.zeros(1, device="cpu" if on_host else dev)
+        dist.all_reduce(flag)              # the others wait here for rank 0
+    # the same tensor-parallel measurement on the in-tree all-reduce, as a child job of every rank
+    # (8 ranks: 16 processes hold a GPU for its duration, two per device)
+    if "tp_oneshot" in plan:
+        free_headline_engine()
+        if rank == 0:
+            # whatever the child job does to this machine, the line as it stands is on record
+            snap = json.dumps(line())
+            print("[bench] line before the in-tree all-reduce child job: " + snap, file=sys.stderr, flush=True)
+            try:
+                os.makedirs("gpurun_out", exist_ok=True)
+                with open(os.path.join("gpurun_out", "bench_line_before_oneshot.json"), "w") as f:
+                    f.write(snap + "\n")
+            except OSError:
+                pass
         try:
             got = run_oneshot_child(args, dist, rank, world, local_rank, dev)
             if got is not None:
@@ -461,6 +574,11 @@ def main(argv=None):
     if watchdog is not None:
         watchdog.cancel()
     emit()
+    if engine is not None and hasattr(engine, "close"):
+        try:
+            engine.close()
+        except Exception:
+            pass
     if dist is not None:
         dist.destroy_process_group()
 

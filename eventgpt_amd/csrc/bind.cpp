@@ -217,17 +217,18 @@ Tensor lowrank_out(const Tensor& x, const Tensor& w, double alpha) {
 
 // ---- few-row projections: GEMM to fp32 split-K slabs + a fused consumer ----
 // partial [nslab, M, N] fp32 (nslab >= 1); the consumers below sum the slabs.
-Tensor linear_partial(const Tensor& x, const Tensor& w) {
+Tensor linear_partial(const Tensor& x, const Tensor& w, int64_t max_split) {
   check_bf16(x, "x"); check_bf16(w, "weight");
   const int64_t K = x.size(-1), N = w.size(0);
   TORCH_CHECK(w.dim() == 2 && w.size(1) == K, "linear_partial: K mismatch");
   TORCH_CHECK(K % 64 == 0 && N % 8 == 0, "linear_partial: K % 64 == 0 and N % 8 == 0");
   const int64_t M = x.numel() / K;
   TORCH_CHECK(M >= 1, "linear_partial: empty input");
-  const int sk = evgpt::gemm_splitk((int)M, (int)N, (int)K);
+  int sk = evgpt::gemm_splitk((int)M, (int)N, (int)K);
+  if (max_split > 0 && sk > max_split) sk = (int)max_split;
   Tensor ws = at::empty({sk, M, N}, x.options().dtype(at::kFloat));
   const int used = evgpt::launch_gemm_partial(bptr(x), bptr(w), ws.data_ptr<float>(), (int)M, (int)N,
-                                              (int)K, (int)K, (int)K, cur_stream());
+                                              (int)K, (int)K, (int)K, cur_stream(), (int)max_split);
   return used == sk ? ws : ws.narrow(0, 0, used);
 }
 
@@ -1071,6 +1072,21 @@ Tensor attn_d512(const Tensor& q, const Tensor& k, const Tensor& v, bool causal,
   return out;
 }
 
+// drafter re-sync of a token-level speculative-decoding round (sd.hip: naive_sd_sync_kernel)
+void naive_sd_sync(const Tensor& t_pos, const Tensor& t_step, const Tensor& t_cur, const Tensor& t_out, int64_t offset,
+                   const Tensor& embed, const Tensor& prompt_last, const Tensor& rows, const Tensor& d_pos0,
+                   const Tensor& d_pos, const Tensor& d_step, const Tensor& d_done, int64_t l_max) {
+  for (const Tensor* t : {&t_pos, &t_step, &t_cur, &t_out, &d_pos0, &d_pos, &d_step, &d_done}) check_i32(*t, "counter");
+  check_bf16(embed, "embed"); check_bf16(prompt_last, "prompt_last"); check_bf16(rows, "rows");
+  const int64_t H = embed.size(1);
+  TORCH_CHECK(embed.dim() == 2 && H % 8 == 0 && prompt_last.numel() == H && rows.numel() == 2 * H && rows.is_contiguous() &&
+              prompt_last.is_contiguous() && t_out.is_contiguous() && l_max >= 2, "naive_sd_sync: rows [2,H], prompt_last [H]");
+  evgpt::launch_naive_sd_sync(t_pos.data_ptr<int>(), t_step.data_ptr<int>(), t_cur.data_ptr<int>(), t_out.data_ptr<int>(),
+                              (int)t_out.size(-1), (int)offset, bptr(embed), (int)embed.size(0), bptr(prompt_last),
+                              bptr_mut(rows), d_pos0.data_ptr<int>(), d_pos.data_ptr<int>(), d_step.data_ptr<int>(),
+                              d_done.data_ptr<int>(), (int)H, (int)l_max, cur_stream());
+}
+
 void sample_top_p(const Tensor& logits, const Tensor& out, double temperature, double top_p,
                   int64_t seed, const Tensor& step, int64_t top_k) {
   check_f32(logits, "logits"); check_i32(out, "out"); check_i32(step, "step");
@@ -1090,7 +1106,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("layernorm(Tensor x, Tensor w, Tensor? b, float eps, int act=0) -> Tensor", &layernorm);
   m.def("linear(Tensor x, Tensor w, Tensor? bias, Tensor? res, int act, bool out_f32) -> Tensor", &linear);
   m.def("linear_swiglu(Tensor x, Tensor w_gate_up) -> Tensor", &linear_swiglu);
-  m.def("linear_partial(Tensor x, Tensor w) -> Tensor", &linear_partial);
+  m.def("linear_partial(Tensor x, Tensor w, int max_split=0) -> Tensor", &linear_partial);
   m.def("lowrank_out(Tensor x, Tensor w, float alpha) -> Tensor", &lowrank_out);
   m.def("linear_t(Tensor a, Tensor w, bool a_t, bool w_t, Tensor? bias, Tensor? res, int act, bool out_f32, int K, Tensor(a!)? out=None) -> Tensor", &linear_t);
   m.def("gemv_max_batch() -> int", []() -> int64_t { return evgpt::gemv_max_batch(); });
@@ -1148,6 +1164,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("gather_rows_dev(Tensor src, Tensor index, int offset, Tensor? n_valid, int rows) -> Tensor", &gather_rows_dev);
   m.def("argmax_from_partials(Tensor pval, Tensor pidx, Tensor(a!) token, int vocab) -> ()", &argmax_from_partials);
   m.def("attn_d512(Tensor q, Tensor k, Tensor v, bool causal, float scale) -> Tensor", &attn_d512);
+  m.def("naive_sd_sync(Tensor t_pos, Tensor t_step, Tensor t_cur, Tensor t_out, int offset, Tensor embed, Tensor prompt_last, Tensor(a!) rows, Tensor(b!) d_pos0, Tensor(c!) d_pos, Tensor(d!) d_step, Tensor(e!) d_done, int l_max) -> ()", &naive_sd_sync);
   m.def("sample_top_p(Tensor logits, Tensor(a!) out, float temperature, float top_p, int seed, Tensor step, int top_k=0) -> ()", &sample_top_p);
   m.def("prefill_rope_kv(Tensor qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos0, int Hq, int Hkv, int D) -> ()", &prefill_rope_kv);
 }

@@ -72,8 +72,10 @@ int gemm_splitk_t(int M, int N, int K);   // K splits for launch_gemm_bf16_t (1 
 void launch_gemm_bf16_t(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,
                         const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,
                         bool a_t, bool w_t, int ka_rows, int kw_rows, hipStream_t st, float* splitk_ws = nullptr, int splitk = 1);
+// max_split > 0 caps the number of K slabs (1: one slab, e.g. a tensor-parallel rank whose
+// contraction is already a slice and whose slab goes straight into a collective)
 int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M, int N, int K,
-                        int lda, int ldw, hipStream_t st);
+                        int lda, int ldw, hipStream_t st, int max_split = 0);
 int gemm_splitk(int M, int N, int K);   // planned split count (1 = none); ws = splitk*M*N floats
 long long gemm_tail_ws_floats(int M, int N, int K);   // unsplit GEMMs: workspace the last-round K split wants (0: none)
 void gemm_enable_tail_splitk(bool on);
@@ -114,6 +116,9 @@ void launch_verify_accept(const float* pval, const int* pidx, int n_part, const 
 void launch_sample_top_p(const float* logits, int* out, int B, int V, float temperature, int top_k,
                          float top_p, unsigned long long seed, const int* step,
                          hipStream_t st);
+void launch_naive_sd_sync(const int* t_pos, const int* t_step, const int* t_cur, const int* t_out, int max_out,
+                          int offset, const bf16_t* embed, int vocab, const bf16_t* prompt_last, bf16_t* rows,
+                          int* d_pos0, int* d_pos, int* d_step, int* d_done, int H, int l_max, hipStream_t st);
 
 // ---- elementwise.hip
 void launch_rmsnorm(const bf16_t* x, const bf16_t* res, const bf16_t* w, bf16_t* y,

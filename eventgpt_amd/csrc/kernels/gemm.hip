@@ -1047,10 +1047,11 @@ void launch_gemm_bf16_t(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, 
 // Projection that stops at the fp32 split-K slabs partial[nslab][M][N]; returns
 // nslab (>= 1).  `partial` holds gemm_splitk(M, N, K) * M * N floats.
 int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M, int N, int K,
-                        int lda, int ldw, hipStream_t st) {
+                        int lda, int ldw, hipStream_t st, int max_split) {
   GemmParams p{A, W, nullptr, nullptr, nullptr, nullptr, M, N, K, lda, ldw, N, ACT_NONE, nullptr,
                nullptr, 1, K, partial, 1, K, K};
-  const int splitk = gemm_splitk(M, N, K);
+  int splitk = gemm_splitk(M, N, K);
+  if (max_split > 0 && splitk > max_split) splitk = max_split;
   if (splitk > 1) {
     const int ksteps = K / 64;
     p.k_per_split = ((ksteps + splitk - 1) / splitk) * 64;

@@ -95,6 +95,51 @@ void launch_verify_accept(const float* pval, const int* pidx, int n_part, const 
                      limit, stats);
 }
 
+// ------------------------------------------------- token-level SD: drafter re-sync
+// Start of one draft/verify round of token-level speculative decoding between two models that
+// share a vocabulary (reference: feasible/naive_speculative_decoding.py:7-60, which re-runs both
+// models over the whole sequence instead).  The verifier's counters say where the sequence
+// stands; the drafter's cache is valid up to the verifier's position minus two at worst (after a
+// round whose drafts were all accepted it has not ingested the last of them).  So every round
+// the drafter begins with a TWO-row pass over [token before the current one, current token] at
+// positions [pos - 1, pos]: row 0 re-writes a slot that is usually already right, row 1 yields
+// the first draft.  This kernel stages those two embedding rows and points the drafter's
+// counters at the verifier's position (plus the difference of the two prompts' lengths); no
+// host read, no conditional catch-up pass.
+__global__ __launch_bounds__(256) void naive_sd_sync_kernel(
+    const int* __restrict__ t_pos, const int* __restrict__ t_step, const int* __restrict__ t_cur,
+    const int* __restrict__ t_out, int max_out, int offset, const bf16_t* __restrict__ embed, int vocab,
+    const bf16_t* __restrict__ prompt_last, bf16_t* __restrict__ rows, int* __restrict__ d_pos0,
+    int* __restrict__ d_pos, int* __restrict__ d_step, int* __restrict__ d_done, int H, int l_max) {
+  const int r = blockIdx.x;   // 0: the token before the current one, 1: the current token
+  const int st = t_step[0];
+  const bf16_t* src;
+  if (r == 0 && (st < 2 || st - 2 >= max_out)) {
+    src = prompt_last;          // nothing but the first token is out: the slot before it is the prompt's last row
+  } else {
+    int tok = r == 0 ? t_out[st - 2] : t_cur[0];
+    if (tok < 0 || tok >= vocab) tok = 0;
+    src = embed + static_cast<size_t>(tok) * H;
+  }
+  for (int c = threadIdx.x; c < (H >> 3); c += 256)
+    *reinterpret_cast<u32x4_t*>(rows + static_cast<size_t>(r) * H + c * 8) = load16(src + c * 8);
+  if (r == 0 && threadIdx.x == 0) {
+    int p = t_pos[0] + offset;                 // the drafter's slot of the current token
+    p = p < 1 ? 1 : (p > l_max - 1 ? l_max - 1 : p);
+    d_pos0[0] = p - 1;
+    d_pos[0] = p;
+    d_step[0] = 0;
+    d_done[0] = 0;
+  }
+}
+
+void launch_naive_sd_sync(const int* t_pos, const int* t_step, const int* t_cur, const int* t_out, int max_out,
+                          int offset, const bf16_t* embed, int vocab, const bf16_t* prompt_last, bf16_t* rows,
+                          int* d_pos0, int* d_pos, int* d_step, int* d_done, int H, int l_max, hipStream_t st) {
+  hipLaunchKernelGGL(naive_sd_sync_kernel, dim3(2), dim3(256), 0, st, t_pos, t_step, t_cur, t_out, max_out, offset,
+                     embed, vocab, prompt_last, rows, d_pos0, d_pos, d_step, d_done, H, l_max);
+}
+
 // ---------------------------------------------------------------- sampler
 // Temperature + top-k + nucleus (top-p) sampling of one token per row, entirely
 // on the device: one 1024-thread block per row keeps the row's probabilities in

@@ -61,6 +61,7 @@ class _Bucket:
         self.new_shard = torch.empty_like(self.grad_shard) if world > 1 else None
         self.pending = 0
         self.work = None
+        self.reduced = False      # this step's gradient already sits, averaged, in grad_shard
 
 
 class ShardedAdamW:
@@ -107,6 +108,7 @@ class ShardedAdamW:
         # written plus 41 GB moved per step).  Whatever reaches ``.grad`` some other way is settled into
         # the slot before the buffer is reduced, so correctness never depends on the shortcut.
         self._sink: Dict[int, torch.Tensor] = {}
+        self._hooks = []
         for b in self.buckets:
             for p, view in zip(b.params, b.grad_views):
                 self._owner[id(p)] = b
@@ -115,14 +117,30 @@ class ShardedAdamW:
                     p._grad_sink_used = True   # until the first zero_grad hands the slot out
                     self._sink[id(p)] = view
                 if self.overlap:
-                    p.register_post_accumulate_grad_hook(self._on_grad)
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._arm()
+
+    def detach(self) -> None:
+        """Let go of the parameters: gradient hooks and direct-gradient slots are removed, so another
+        optimizer can take the same parameters over (they keep their current values and storage)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for b in self.buckets:
+            for p in b.params:
+                if id(p) in self._sink:
+                    del p._grad_sink
+                    if hasattr(p, "_grad_sink_used"):
+                        del p._grad_sink_used
+                p.grad = None
+        self._sink = {}
 
     # ------------------------------------------------------------- hooks / comm
     def _arm(self) -> None:
         for b in self.buckets:
             b.pending = len(b.params)
             b.work = None
+            b.reduced = False
 
     def _settle(self, p: torch.nn.Parameter) -> None:
         """Make the flat buffer hold ``p``'s gradient and ``p.grad`` be its slot again."""
@@ -143,9 +161,14 @@ class ShardedAdamW:
         if b.pending == 0:
             self._launch_reduce(b)
 
+    #: gradient collectives launched so far (tests count them)
+    reduces_launched = 0
+
     def _launch_reduce(self, b: _Bucket) -> None:
         if not self.distributed or self.world == 1:
+            b.reduced = True
             return      # grad_shard aliases the flat gradient
+        self.reduces_launched += 1
         if self.on_rccl:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
@@ -160,19 +183,27 @@ class ShardedAdamW:
             dist.reduce_scatter_tensor(b.grad_shard, b.flat_grad, op=dist.ReduceOp.SUM,
                                        group=self.group)
             b.grad_shard.div_(self.world)
+        if b.work is None:
+            b.reduced = True              # synchronous paths are complete here; async ones once waited for
 
     def _finish_reduces(self) -> None:
+        """Every bucket's averaged gradient shard is in place afterwards.  Idempotent within a step:
+        a bucket that has been reduced (by a hook, or by an earlier call -- ``global_grad_norm()``
+        before ``step()``) is not reduced again until ``zero_grad()`` re-arms it."""
         if self._sink:
             for b in self.buckets:
-                if b.work is None:
+                if b.work is None and not b.reduced:
                     for p in b.params:
                         self._settle(p)
         for b in self.buckets:
+            if b.reduced:
+                continue
             if b.work is None:            # not launched from a hook (no overlap, or a parameter without gradient)
                 self._launch_reduce(b)
             if b.work is not None:        # (a one-rank group has nothing in flight)
                 b.work.wait()
                 b.work = None
+                b.reduced = True
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
@@ -311,5 +342,11 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
     """Make every rank start from rank ``src``'s weights."""
     if not (dist.is_available() and dist.is_initialized()):
         return
+    on_host = dist.get_backend(group) == "gloo"
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        if on_host and t.is_cuda:               # gloo only ever sees host tensors
+            host = t.data.cpu()
+            dist.broadcast(host, src=src, group=group)
+            t.data.copy_(host)
+        else:
+            dist.broadcast(t.data, src=src, group=group)

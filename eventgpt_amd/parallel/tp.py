@@ -264,6 +264,62 @@ class TensorParallelEngine(GenerationEngine):
                 else:
                     ar.close()
 
+    # ------------------------------------------------------- collective health / teardown
+    def check_collectives(self) -> None:
+        """Did a bounded device wait of the in-tree all-reduces (one-shot: decode / verify rows,
+        two-shot: prefill) give up?  After a give-up a rank holds other sums than its peers, so
+        this is called wherever the host already waits for the device -- the end of a prefill,
+        the EOS polls of ``generate``, the batch scheduler's poll -- and the verdict is
+        MIN-reduced over the group: every rank raises together instead of drifting apart.
+
+        Skew bound: a wait gives up after ``spin_limit`` polls (2^18, a few hundred ms).  Ranks
+        enter a collective further apart than that only when one of them stalls on the host
+        (first-launch module load, a garbage collection, an admission only it performs), which is
+        why graph capture ends in a barrier and why eager steps are checked here."""
+        if self.oneshot is None and self.twoshot is None:
+            return
+        msg = None
+        for ar in (self.oneshot, self.twoshot):
+            if ar is None:
+                continue
+            try:
+                ar.check()
+            except RuntimeError as e:
+                msg = str(e)
+                ar.clear_errors()
+        ok = torch.tensor([0 if msg else 1], dtype=torch.int32, device="cpu" if self._gloo else self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.tp_group)
+        if int(ok.item()) == 0:
+            raise RuntimeError("tensor-parallel all-reduce: a device-side wait timed out on "
+                               + ("this rank: " + msg if msg else "another rank")
+                               + "; the ranks no longer hold the same sums (rebuild the engine, or run with "
+                                 "allreduce='rccl')")
+
+    def _poll_hook(self) -> None:
+        self.check_collectives()
+
+    def close(self) -> None:
+        """Tear the peer mappings down in an order that does not depend on who drops the engine
+        first: finish this rank's work, wait until every rank has (nobody pushes into a buffer any
+        more), unmap the peers' buffers, wait again (nobody still maps mine), release mine."""
+        one, two = self.oneshot, self.twoshot
+        self.oneshot = self.twoshot = None
+        if one is None and two is None:
+            return
+        self._graph_greedy.clear()
+        self._graph_logits = None
+        self._verify_graphs.clear()          # captured launches hold the buffers' addresses
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.tp_group)
+        for ar in (one, two):
+            if ar is not None:
+                ar.close()
+        dist.barrier(group=self.tp_group)
+        for ar in (one, two):
+            if ar is not None:
+                ar.buf = None
+        self.allreduce_kind = "gloo" if self._gloo else "rccl"
+
     def _capture_or_eager(self, fn):
         """A captured step is first replayed by ranks that finished capturing at different times.
         The library collective waits for the late ones as long as it takes; the in-tree all-reduce
@@ -319,7 +375,18 @@ class TensorParallelEngine(GenerationEngine):
         dist.all_reduce(t, group=self.tp_group)
         return t
 
+    #: a rank's slice of a row-parallel contraction up to this long is multiplied as ONE slab (the K
+    #: split across the ranks already is the split), so the library collective runs on the GEMM's
+    #: output in place: projection, all-reduce, residual + norm -- two launches around the collective
+    ONE_SLAB_K = 2048
+
+    def _row_partial(self, x, w):
+        if self.tp_world > 1 and self.oneshot is None and w.shape[1] <= self.ONE_SLAB_K:
+            return self.raw.linear_partial(x, w, 1)
+        return self.raw.linear_partial(x, w)
+
     def _reduce_residual_norm(self, partial, x, norm_w):
+        """``partial`` is a fresh ``_row_partial`` result (this engine's to overwrite)."""
         if self.tp_world == 1:
             return super()._reduce_residual_norm(partial, x, norm_w)
         raw = self.raw
@@ -333,9 +400,8 @@ class TensorParallelEngine(GenerationEngine):
                 if norm_w is not None and not fuse_norm:
                     xn = raw.rmsnorm(x_out, norm_w, self.eps)
                 return x_out, (xn if norm_w is not None else x_out.new_empty(0))
+        # library collective: on the single slab in place, or on the slabs' sum (longer local contractions)
         total = raw.sum_slabs(partial) if partial.shape[0] > 1 else partial
-        if total.data_ptr() == partial.data_ptr():
-            total = partial.clone()          # the caller's slab tensor is not ours to overwrite
         self._allreduce_f32(total)
         return raw.reduce_residual_norm(total, x.view(M, N), norm_w, self.eps, None)
 
@@ -433,6 +499,7 @@ class TensorParallelEngine(GenerationEngine):
             for b, emb, last in zip(group_s, group_e, lasts):
                 self.x[b].copy_(last)
                 self.pos[b] = emb.shape[0] - 1      # the commit advances it to the prompt length
+                self._pos_hi = max(self._pos_hi, int(emb.shape[0]))   # host bound behind cache_room()
             i = j
 
     def _layers_step(self) -> None:
@@ -453,10 +520,10 @@ class TensorParallelEngine(GenerationEngine):
                                    self.cos, self.sin, self.pos, B, 1, self.Hq, self.Hkv, self.D)
                 raw.decode_attn(self.q, l.k_cache, l.v_cache, self.attn, self.part_o, self.part_ml,
                                 self.pos, self.nsplit, self.scale)
-                x, xn = self._reduce_residual_norm(raw.linear_partial(self.attn, l.w_o), x, l.norm2)
+                x, xn = self._reduce_residual_norm(self._row_partial(self.attn, l.w_o), x, l.norm2)
                 h = raw.reduce_swiglu(raw.linear_partial(xn, l.w_gate_up))
                 nxt = self.layers[i + 1].norm1 if i + 1 < n else None
-                x, xn = self._reduce_residual_norm(raw.linear_partial(h, l.w_down), x, nxt)
+                x, xn = self._reduce_residual_norm(self._row_partial(h, l.w_down), x, nxt)
             self.x.copy_(x)
             return
         lead = self.tp_rank == 0
@@ -526,14 +593,25 @@ class TensorParallelEngine(GenerationEngine):
         self.reset()
         self._prefill_slots(list(range(self.B)), list(embeds_list))
         self._logits_and_commit(greedy=True)
+        self._after_prefill()
+
+    def _after_prefill(self) -> None:
+        """The in-tree collectives of a prefill are checked once its work is done (one device sync per
+        prompt, where the library collective would have synchronised the ranks anyway)."""
+        if self.oneshot is not None or self.twoshot is not None:
+            torch.cuda.synchronize(self.device)
+            self.check_collectives()
 
     def prefill(self, embeds, batch: int = 0, start: Optional[int] = None,
                 select: Optional[str] = "greedy", return_hidden: bool = False):
         if self.B == 1:
-            return super().prefill(embeds, batch, start, select, return_hidden)
-        if select is not None:
-            raise ValueError("with several sequences use prefill_batch (one commit for all)")
-        return super().prefill(embeds, batch, start, None, return_hidden)
+            out = super().prefill(embeds, batch, start, select, return_hidden)
+        else:
+            if select is not None:
+                raise ValueError("with several sequences use prefill_batch (one commit for all)")
+            out = super().prefill(embeds, batch, start, None, return_hidden)
+        self._after_prefill()
+        return out
 
     # ------------------------------------------------------ slot-wise scheduling
     def enable_slot_masks(self) -> None:
@@ -561,6 +639,7 @@ class TensorParallelEngine(GenerationEngine):
         self._logits_and_commit(greedy=True)
         keep[list(slots)] = 1
         self.active.copy_(keep)
+        self._after_prefill()
 
     def park(self, slots: Sequence[int]) -> None:
         """Stop advancing ``slots`` (finished or cancelled sequences)."""

@@ -98,6 +98,7 @@ class ContinuousBatcher:
         e = self.e
         step = e.step.tolist()                 # one small D2H copy each
         done = e.done.tolist()
+        e._poll_hook()                         # (tensor-parallel engines: did a collective's wait give up?)
         now = time.perf_counter()
         retire = []
         for s, r in self.running.items():

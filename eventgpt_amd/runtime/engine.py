@@ -345,6 +345,11 @@ class GenerationEngine:
         return (3 < rows <= self.fused_rows and self.H % 64 == 0
                 and self.I % 64 == 0 and (self.Hq * self.D) % 64 == 0)
 
+    def _row_partial(self, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """fp32 split-K slabs ``[nslab, M, N]`` of a row-parallel projection (``o_proj`` / ``down_proj``)
+        for ``_reduce_residual_norm``."""
+        return self.raw.linear_partial(x, w)
+
     def _reduce_residual_norm(self, partial, x, norm_w):
         """``(x + bf16(sum of the split-K slabs), RMSNorm of that * norm_w)`` of a row-parallel
         projection's partials ``[nslab, M, N]``.  A tensor-parallel engine also sums over the
@@ -365,11 +370,11 @@ class GenerationEngine:
             raw.reduce_rope_kv(raw.linear_partial(xn, self._w(l, "w_qkv")), q, kc, vc, self.cos, self.sin, pos0,
                                1, S, self.Hq, self.Hkv, self.D)
             raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
-            x, xn = self._reduce_residual_norm(raw.linear_partial(o.view(S, self.Hq * self.D), self._w(l, "w_o")),
+            x, xn = self._reduce_residual_norm(self._row_partial(o.view(S, self.Hq * self.D), self._w(l, "w_o")),
                                                x, l.norm2)
             h = raw.reduce_swiglu(raw.linear_partial(xn, self._w(l, "w_gate_up")))
             nxt = self.layers[i + 1].norm1 if i + 1 < n else None
-            x, xn = self._reduce_residual_norm(raw.linear_partial(h, self._w(l, "w_down")), x, nxt)
+            x, xn = self._reduce_residual_norm(self._row_partial(h, self._w(l, "w_down")), x, nxt)
         return x.view(1, S, self.H)
 
     def _forward_rows(self, embeds: torch.Tensor, batch: int, pos0: torch.Tensor) -> torch.Tensor:
@@ -482,6 +487,10 @@ class GenerationEngine:
         self.raw.commit_token(self.part_val, self.part_idx, self.n_part, self.sampled, self.embed,
                               self.x, self.out_tokens, self.step, self.pos, self.done,
                               self.cur_token, self.eos, self.active)
+
+    def _poll_hook(self) -> None:
+        """Called where the host has just waited for the device anyway (EOS polls); a
+        tensor-parallel engine checks its collectives' error words here."""
 
     def _step_greedy(self) -> None:
         self._layers_step()
@@ -633,6 +642,7 @@ class GenerationEngine:
         n = int(self.step[0].item())
         budget = min(max_new_tokens, self.max_out)
         while n < budget and not int(self.done[0].item()):
+            self._poll_hook()
             chunk = min(self.poll_every, budget - n)
             for _ in range(chunk):
                 self.decode_step(greedy)

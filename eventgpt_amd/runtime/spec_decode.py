@@ -145,30 +145,97 @@ class AdapterDraftHead:
 
 class NaiveSpeculativeDecoder:
     """Greedy token-level SD.  ``draft`` and ``target`` are ``GenerationEngine``s over
-    the same vocabulary; both keep their KV caches and roll back by position."""
+    the same vocabulary; both keep their KV caches and roll back by position
+    [feasible/naive_speculative_decoding.py:7-60 re-runs both models over the whole
+    sequence for every draft token and every verification].
+
+    Device-resident rounds (the default): one round -- point the drafter at the target's
+    position and stage its two input rows (``naive_sd_sync``), a two-row drafter pass that
+    yields the first draft, gamma - 1 drafter decode steps, the target's verify pass over
+    gamma + 1 rows and the fused accept kernel -- is ONE captured hipGraph.  The two-row
+    start replaces the conditional catch-up pass of a host-driven loop (after a round whose
+    drafts were all accepted the drafter has not ingested the last of them): re-writing the
+    slot before the current token costs the second row of a weight-streaming pass, and
+    needs no decision the host would have to read a counter for.  The host replays the
+    graph ``poll_every`` times and then reads six integers.
+    """
 
     def __init__(self, draft_engine, target_engine, tokenizer=None):
         self.draft, self.target, self.tokenizer = draft_engine, target_engine, tokenizer
+        self._graphs = {}
+        self._rows = None
+
+    # ------------------------------------------------------ device-resident rounds
+    def _state(self) -> None:
+        d, t = self.draft, self.target
+        if self._rows is None:
+            dev = d.device
+            self._rows = torch.zeros(2, d.H, dtype=torch.bfloat16, device=dev)
+            self._prompt_last = torch.zeros(d.H, dtype=torch.bfloat16, device=dev)
+            self._pos0 = torch.zeros(1, dtype=torch.int32, device=dev)
+        if t.sd_limit is None:
+            t.sd_limit = torch.zeros(1, dtype=torch.int32, device=t.device)
+            t.sd_stats = torch.zeros(4, dtype=torch.int32, device=t.device)
+            t._verify_graphs.clear()         # earlier verify graphs were captured without them
+
+    def _round_body(self, gamma: int, offset: int) -> None:
+        d, t = self.draft, self.target
+        raw = t.raw
+        raw.naive_sd_sync(t.pos, t.step, t.cur_token, t.out_tokens, offset, d.embed, self._prompt_last,
+                          self._rows, self._pos0, d.pos, d.step, d.done, d.l_max)
+        x = d._forward_rows(self._rows, 0, self._pos0)       # two rows: positions pos - 1, pos
+        d.x[0].copy_(x[0, -1])
+        d._logits_and_commit(greedy=True)                    # draft 1; the commit stages its embedding
+        for _ in range(gamma - 1):
+            d._layers_step()
+            d._logits_and_commit(greedy=True)
+        t._verify_body(d.out_tokens[0, :gamma], gamma)
+
+    def _round_graph(self, gamma: int, offset: int):
+        d, t = self.draft, self.target
+        key = (gamma, offset, t.eos)
+        g = self._graphs.get(key)
+        if g is None:
+            keep_t = (t.out_tokens, t.sd_result, t.sd_stats, d.step, d.pos, d.done, d.cur_token, d.x, d.out_tokens)
+            keep = [x.clone() for x in keep_t]
+            try:
+                g = t._capture(lambda: self._round_body(gamma, offset))
+            finally:
+                for x, k in zip(keep_t, keep):
+                    x.copy_(k)
+            self._graphs[key] = g
+        return g
 
     @torch.no_grad()
     def generate(self, draft_embeds: torch.Tensor, target_embeds: Optional[torch.Tensor] = None,
-                 max_new_tokens: int = 50, num_draft_tokens: int = 5, eos_token_id: int = -1):
+                 max_new_tokens: int = 50, num_draft_tokens: int = 5, eos_token_id: int = -1,
+                 device_loop: bool = True, poll_every: int = 4):
         """Returns ``(tokens, acceptance_history)``; ``tokens`` equals the target's own
-        greedy continuation of its prompt."""
+        greedy continuation of its prompt.  The history has one entry per round when the
+        host drives the rounds and one per ``poll_every`` rounds (their mean) otherwise;
+        ``self.stats`` holds the totals of the last call."""
         d, t = self.draft, self.target
         target_embeds = draft_embeds if target_embeds is None else target_embeds
-        d.eos = t.eos = eos_token_id
+        t.eos = eos_token_id
+        d.eos = -1                       # the drafter proposes; only the target ends a sequence
         d.reset(); t.reset()
         gamma = num_draft_tokens
+        if not 1 <= gamma <= 63:
+            raise ValueError(f"1..63 draft tokens per round, got {gamma}")
+        if d.embed.shape[0] != t.embed.shape[0]:
+            raise ValueError("token-level speculative decoding needs one vocabulary on both sides")
         # every verify appends up to gamma+1 cache rows on both sides: keep the budget inside
         room = min(t.l_max - target_embeds.shape[0], d.l_max - draft_embeds.shape[0]) - (gamma + 1)
         if room < 1:
             raise ValueError(f"prompt of {target_embeds.shape[0]} / {draft_embeds.shape[0]} tokens leaves no room "
                              f"for speculative rounds of {gamma} in caches of {t.l_max} / {d.l_max}")
-        max_new_tokens = min(max_new_tokens, room)
+        max_new_tokens = min(max_new_tokens, room, t.max_out, d.max_out)
         t.prefill(target_embeds, select="greedy")          # first token comes from the target
         d.prefill(draft_embeds, select=None)
         offset = draft_embeds.shape[0] - target_embeds.shape[0]
+        self.stats = SDStats()
+        if device_loop:
+            return self._generate_device(draft_embeds, max_new_tokens, gamma, offset, poll_every)
         history: List[float] = []
         # one read per round: [n_accepted, next, emitted, step, done, pos] of the last verify
         info = [0, 0, 0, 1, int(t.done[0].item()), target_embeds.shape[0]]
@@ -185,13 +252,50 @@ class NaiveSpeculativeDecoder:
             info = t.sd_result[:6].tolist()
             n_acc = info[0]
             history.append(n_acc / gamma)
+            self.stats.total_drafted += gamma
+            self.stats.total_accepted += n_acc
+            self.stats.iterations += 1
             if n_acc == gamma and not info[4]:
                 # every draft token was accepted: the drafter has not yet ingested the
                 # last one (its cache holds pos < base+gamma)
                 d.pos.fill_(base + gamma)
                 d.x[0].copy_(d.embed[draft[gamma - 1].long()])
                 d._layers_step()
-        return _emitted(t)[:max_new_tokens], history
+        toks = _emitted(t)[:max_new_tokens]
+        self.stats.tokens = int(toks.shape[0])
+        return toks, history
+
+    def _generate_device(self, draft_embeds, max_new_tokens: int, gamma: int, offset: int, poll_every: int):
+        d, t = self.draft, self.target
+        self._state()
+        self._prompt_last.copy_(draft_embeds[-1].to(torch.bfloat16))
+        t.sd_result.zero_()
+        t.sd_limit.fill_(max_new_tokens)
+        t.sd_stats.zero_()
+        graph = self._round_graph(gamma, offset) if t.use_graph else None
+        history: List[float] = []
+        step, done = int(t.step[0].item()), int(t.done[0].item())
+        seen = [0, 0]
+        while step < max_new_tokens and not done:
+            for _ in range(min(poll_every, max_new_tokens - step)):    # a round emits at least one token
+                if graph is not None:
+                    graph.replay()
+                else:
+                    self._round_body(gamma, offset)
+            info = torch.cat([t.sd_result[:6], t.sd_stats[:3]]).tolist()   # the only host read of these rounds
+            step, done = info[3], info[4]
+            drafted, accepted = info[6] - seen[0], info[7] - seen[1]
+            seen = [info[6], info[7]]
+            if drafted:
+                history.append(accepted / drafted)
+        st = t.sd_stats.tolist()
+        self.stats.total_drafted, self.stats.total_accepted, self.stats.iterations = st[0], st[1], st[2]
+        t.sd_limit.fill_(1 << 30)
+        t._pos_hi = int(t.pos[0].item())
+        d._pos_hi = int(d.pos[0].item())
+        toks = _emitted(t)[:max_new_tokens]
+        self.stats.tokens = int(toks.shape[0])
+        return toks, history
 
 
 class SpecDecodeEngine:

@@ -23,6 +23,8 @@ def _train(model, opt, info, x, y, steps, norms):
         opt.zero_grad()
         loss = (model(xb) - yb).pow(2).mean()
         loss.backward()
+        if step % 2:                    # reading the norm first must not reduce the gradients a second time
+            opt.global_grad_norm()
         norms.append(float(opt.step(max_grad_norm=0.5)))
 
 
@@ -58,7 +60,7 @@ def main(out_path, resume=False):
     if info.rank == 0:
         same = all(torch.equal(gathered[0], t) for t in gathered)
         json.dump({"params": flat.tolist(), "norms": norms, "ranks_agree": same,
-                   "n_buckets": len(opt.buckets), "world": info.world,
+                   "n_buckets": len(opt.buckets), "world": info.world, "reduces_launched": opt.reduces_launched,
                    "padding": [b.padded - b.numel for b in opt.buckets]}, open(out_path, "w"))
     shutdown()
 

@@ -52,6 +52,11 @@ def test_single_gpu_default_does_not_launch():
     child = bench.oneshot_child_command(bench.parse_args(["--gpus", "4", "--steps", "20", "--settle-steps", "50"]), 4)
     assert child[child.index("--allreduce") + 1] == "auto" and child[child.index("--settle-steps") + 1] == "50"
     assert "--no-oneshot-extra" in child and "--no-dp-extra" in child      # the child job does not nest another
+    assert "--no-dp-train-extra" in child and "--no-sd-extra" in child
+    # the child job exists at the full width of a node too (two processes per GPU for its duration)
+    child8 = bench.oneshot_child_command(bench.parse_args(["--gpus", "8"]), 8)
+    assert child8[child8.index("--gpus") + 1] == "8" and child8[child8.index("--allreduce") + 1] == "auto"
+    assert float(child8[child8.index("--extras-timeout") + 1]) >= 60
     cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "5"], 29999)
     assert "--nproc-per-node=8" in cmd and cmd[-4:] == ["--gpus", "8", "--steps", "5"]
     assert "127.0.0.1" in cmd
@@ -81,6 +86,16 @@ def test_multi_rank_flow_rehearsal_on_one_gpu(n):
     one = got["tp_oneshot"]
     assert "error" not in one and one["tp_allreduce"] == "oneshot" and one["tokens_per_s"] > 0, one
     assert "error" not in one["tp_batch32"], one
+    # a fine-tuning step per rank through the sharded AdamW over the run's group, both stages
+    dpt = got["dp_train"]
+    assert "error" not in dpt and dpt["global_batch"] == n, dpt
+    for stage in ("projector", "lora"):
+        assert dpt[stage]["no_overlap"]["ms_per_step"] > 0 and dpt[stage]["trainable_parameters"] > 0, dpt
+    # prefill hiding through the two-model scheduler (one device here: the rehearsal has no second GPU)
+    sd = got["sd_two_gpu"]
+    assert "error" not in sd and sd["one_gpu_two_streams"]["prefill_hiding_ms"] > 0, sd
+    assert "same_tokens_as_verifier" in sd["one_gpu_two_streams"]      # (may differ at bf16 near-ties)
+    assert got["ms_per_step_cold"] > 0
 
 
 @pytest.mark.gpu
@@ -101,3 +116,4 @@ def test_extras_time_limit_keeps_the_headline_line():
     assert got["n_gpus"] == 2 and got["value"] > 0
     assert "not finished" in got["tp_batch32"]["error"] and "not finished" in got["dp_replicas"]["error"]
     assert "not finished" in got["tp_oneshot"]["error"]
+    assert "not finished" in got["dp_train"]["error"] and "not finished" in got["sd_two_gpu"]["error"]

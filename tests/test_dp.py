@@ -41,6 +41,8 @@ def test_sharded_adamw_two_ranks_matches_adamw(tmp_path):
     got = json.load(open(out))
     want, norms = _reference()
     assert got["ranks_agree"] and got["n_buckets"] >= 2
+    # one gradient collective per bucket and step, also on the steps that read the norm before stepping
+    assert got["reduces_launched"] == 6 * got["n_buckets"], got["reduces_launched"]
     assert torch.allclose(torch.tensor(got["params"]), want, atol=2e-5), \
         (torch.tensor(got["params"]) - want).abs().max()
     assert torch.allclose(torch.tensor(got["norms"]), torch.tensor(norms), rtol=1e-4)

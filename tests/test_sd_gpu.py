@@ -96,22 +96,76 @@ def test_verify_graph_replays_match_eager(target, dev):
     assert torch.equal(eager.out_tokens[0, :n].long(), greedy[:n])
 
 
-def test_naive_sd_is_lossless(target, drafter, dev):
+@pytest.mark.parametrize("device_loop", [True, False])
+def test_naive_sd_is_lossless(target, drafter, dev, device_loop):
     from eventgpt_amd.runtime.spec_decode import NaiveSpeculativeDecoder
     emb = _emb(dev, 33, seed=3)
     t_eng = target.engine(max_len=512, max_new_tokens=128)
     greedy = t_eng.generate(emb, 30, eos_token_id=-1)
     d_eng = drafter.engine(max_len=512, max_new_tokens=128)
-    toks, hist = NaiveSpeculativeDecoder(d_eng, t_eng).generate(emb, None, 30, 4, -1)
+    sd = NaiveSpeculativeDecoder(d_eng, t_eng)
+    toks, hist = sd.generate(emb, None, 30, 4, -1, device_loop=device_loop)
     _assert_lossless(t_eng, emb, toks, greedy[:len(toks)])
-    assert len(toks) >= 30
+    assert len(toks) >= 30 and sd.stats.iterations > 0 and sd.stats.total_drafted == 4 * sd.stats.iterations
     # the target drafting for itself accepts everything
-    import copy
     twin = EventChatModel.from_config(_cfg(3), torch.bfloat16, dev, seed=11)
-    toks2, hist2 = NaiveSpeculativeDecoder(twin.engine(max_len=512, max_new_tokens=128),
-                                           t_eng).generate(emb, None, 30, 4, -1)
+    sd2 = NaiveSpeculativeDecoder(twin.engine(max_len=512, max_new_tokens=128), t_eng)
+    toks2, hist2 = sd2.generate(emb, None, 30, 4, -1, device_loop=device_loop)
     _assert_lossless(t_eng, emb, toks2[:30], greedy[:30])
-    assert sum(hist2) / len(hist2) > 0.9             # a drafter with the target's weights is accepted (ties aside)
+    assert sd2.stats.accept_rate > 0.9               # a drafter with the target's weights is accepted (ties aside)
+    assert sd2.stats.iterations <= 8                 # 30 tokens in rounds of up to 5
+
+
+def test_naive_sd_device_rounds_replay_and_prompt_offset(target, drafter, dev):
+    """The captured round is replayed across calls with other work in between, with drafter and
+    target prompts of different lengths (the drafter's positions are the target's plus an offset),
+    and with an EOS id that ends the sequence inside a round."""
+    from eventgpt_amd.runtime.spec_decode import NaiveSpeculativeDecoder
+    t_emb, d_emb = _emb(dev, 57, seed=21), _emb(dev, 23, seed=22)
+    t_eng = target.engine(max_len=512, max_new_tokens=128)
+    d_eng = drafter.engine(max_len=512, max_new_tokens=128)
+    sd = NaiveSpeculativeDecoder(d_eng, t_eng)
+    greedy = t_eng.generate(t_emb, 40, eos_token_id=-1)
+    for rep in range(3):
+        toks, _ = sd.generate(d_emb, t_emb, 40, 3, -1, poll_every=2 + rep)
+        _ = (torch.randn(256, 256, device=dev) @ torch.randn(256, 256, device=dev)).sum().item()
+        _assert_lossless(t_eng, t_emb, toks, greedy[:len(toks)])
+        assert len(toks) == 40
+    assert len(sd._graphs) == 1
+    # the host-driven loop gives the same tokens from the same prompts
+    toks_h, _ = sd.generate(d_emb, t_emb, 40, 3, -1, device_loop=False)
+    _assert_lossless(t_eng, t_emb, toks_h, greedy[:40])
+    # EOS: stop at the first occurrence of a token of the greedy answer
+    k = next(i for i in range(3, 30) if int(greedy[i]) not in greedy[:i].tolist())
+    toks_e, _ = sd.generate(d_emb, t_emb, 40, 3, int(greedy[k]))
+    assert int(t_eng.done[0]) == 1 and int(toks_e[-1]) == int(greedy[k])
+    _assert_lossless(t_eng, t_emb, toks_e, greedy[:len(toks_e)])
+
+
+@pytest.mark.timeout(600)
+def test_naive_sd_lossless_at_7b_layer_geometry(dev):
+    """Two layers of the 7B geometry (4096 wide, 32 heads of 128, 11008 intermediate, 32003 tokens):
+    a drafter with the target's own weights is accepted throughout, an unrelated one almost never,
+    and both leave the target's greedy answer."""
+    from eventgpt_amd.runtime.spec_decode import NaiveSpeculativeDecoder
+    cfg = EventChatConfig(vocab_size=32003, hidden_size=4096, intermediate_size=11008, num_hidden_layers=2,
+                          num_attention_heads=32, max_position_embeddings=4096, torch_dtype="bfloat16")
+    tgt = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=5)
+    twin = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=5)
+    other = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=6)
+    g = torch.Generator(device=dev).manual_seed(1)
+    emb = (torch.randn(300, 4096, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    d_emb = emb[:120].clone()
+    t_eng = tgt.engine(max_len=1024, max_new_tokens=128)
+    greedy = t_eng.generate(emb, 48, eos_token_id=-1)
+    sd = NaiveSpeculativeDecoder(twin.engine(max_len=1024, max_new_tokens=128), t_eng)
+    toks, _ = sd.generate(emb, None, 48, 5, -1)
+    _assert_lossless(t_eng, emb, toks, greedy[:48])
+    assert sd.stats.accept_rate > 0.85 and sd.stats.iterations <= 12
+    sd0 = NaiveSpeculativeDecoder(other.engine(max_len=1024, max_new_tokens=128), t_eng)
+    toks0, _ = sd0.generate(d_emb, emb, 48, 5, -1)
+    _assert_lossless(t_eng, emb, toks0, greedy[:48])
+    assert sd0.stats.iterations >= 20
 
 
 @pytest.mark.parametrize("mode,level", [("adapter", 1), ("adapter", 4), ("vlm_only", 5), ("fused", 6)])
