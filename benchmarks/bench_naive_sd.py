@@ -10,6 +10,13 @@ Two regimes bracket what any trained drafter can do with random-initialised weig
 * ``indep``  an unrelated 7B drafter on its own 636-token prompt: almost nothing is accepted -- the overhead
              bound (one token per round).
 
+Gaussian random weights give nearly flat logits: the best two of 32 003 candidates are closer than the bf16
+kernels' rounding a quarter of the time, so a one-row decode step and a multi-row verify pass of the SAME
+model often pick different tokens, which no trained model does.  ``--peaked`` (the default) therefore ties
+the LM head to a permutation of the (scaled-up) token embeddings: the next token is a fixed function of the
+current one with a wide margin, like a confident trained model; everything else stays random, and the time
+of a kernel does not depend on the values it multiplies.  ``--no-peaked`` keeps plain Gaussian weights.
+
     python benchmarks/bench_naive_sd.py [--gammas 3,5,8] [--tokens 96] [--regime both] [--layers 32]
 """
 import argparse
@@ -35,6 +42,7 @@ ap.add_argument("--poll-every", type=int, default=4)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--host-loop", action="store_true", help="also time the host-driven loop")
 ap.add_argument("--json", default=None, help="write the rows to this file")
+ap.add_argument("--no-peaked", action="store_true", help="plain Gaussian weights (near-tied logits)")
 args = ap.parse_args()
 
 dev = torch.device("cuda")
@@ -44,6 +52,12 @@ cfg = EventChatConfig(vocab_size=32003, hidden_size=4096, intermediate_size=1100
 
 def build(seed):
     m = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=seed)
+    if not args.no_peaked:
+        with torch.no_grad():
+            gen = torch.Generator(device=dev).manual_seed(1000 + seed)
+            perm = torch.randperm(cfg.vocab_size, device=dev, generator=gen)
+            m.model.embed_tokens.weight.mul_(150.0)           # the token's own row dominates the residual stream
+            m.lm_head.weight.copy_(m.model.embed_tokens.weight[perm] / 150.0)
     return m, m.engine(max_len=4096, max_new_tokens=args.tokens + 80)
 
 
@@ -125,7 +139,8 @@ for regime in regimes:
             n_tok = int(toks.shape[0]) - 1             # tokens produced by the rounds (the first comes from the prefill)
             row = {"regime": regime, "gamma": gamma, "loop": "device" if device_loop else "host",
                    "rounds": st.iterations, "accept_rate": round(st.accept_rate, 4), "tokens": n_tok,
-                   "lossless": chk["lossless"], "exact": chk["exact"]}
+                   "lossless": chk["lossless"], "exact": chk["exact"], "first_mismatch": chk["first_mismatch"],
+                   "mismatch_logit_gap": chk["mismatch_logit_gap"]}
             if best is not None:
                 ms, reads = best
                 row.update({"ms": round(ms, 2), "ms_per_round": round(ms / st.iterations, 3),
@@ -137,7 +152,8 @@ for regime in regimes:
     torch.cuda.empty_cache()
 
 out = {"verifier_only_ms_per_token": round(base / (args.tokens - 1), 4), "verifier_prompt": args.verifier_prompt,
-       "drafter_prompt": args.drafter_prompt, "layers": args.layers, "tokens": args.tokens, "rows": rows}
+       "drafter_prompt": args.drafter_prompt, "layers": args.layers, "tokens": args.tokens,
+       "peaked_logits": not args.no_peaked, "rows": rows}
 if args.json:
     os.makedirs(os.path.dirname(os.path.abspath(args.json)), exist_ok=True)
     with open(args.json, "w") as f:

@@ -58,7 +58,8 @@ def dp_train_extra(model_kind: str, dist, dev, world: int, rank: int, steps: int
                                                    seed=100 * rank, **ev))
     out: Dict = {"global_batch": world, "steps": steps, "backend": backend}
     for tune in ("projector", "lora"):
-        tr = SFTTrainer(model, tok, ds, info, tune=tune, output_dir=tempfile.mkdtemp(prefix="evgpt_dpx_out_"))
+        tr = SFTTrainer(model, tok, ds, info, tune=tune, output_dir=tempfile.mkdtemp(prefix="evgpt_dpx_out_"),
+                        broadcast=False)        # every rank built the model from the same seed
         model.train()
         row = {"trainable_parameters": sum(p.numel() for p in tr.params)}
         for label, overlap in (("overlap", True), ("no_overlap", False)):

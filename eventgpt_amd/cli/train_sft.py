@@ -122,13 +122,13 @@ class SFTTrainer:
                  num_frames: int = 5, event_image_key: str = "event_image", learning_rate: float = 1e-3,
                  weight_decay: float = 0.0, warmup_ratio: float = 0.03, gradient_accumulation: int = 1,
                  max_len: int = 2048, output_dir: str = "tasks/sft", lora: Optional[Dict] = None,
-                 dgrad_copies: bool = True):
+                 dgrad_copies: bool = True, broadcast: bool = True):
         self.model, self.tok, self.ds, self.info = model, tokenizer, dataset, info
         self.tune, self.num_frames, self.key = tune, num_frames, event_image_key
         self.accum, self.max_len, self.out = max(1, gradient_accumulation), max_len, output_dir
         self.lr, self.warmup_ratio = learning_rate, warmup_ratio
         self.params = select_trainable(model, tune, **(lora or {}))
-        if info.world > 1:
+        if info.world > 1 and broadcast:       # (off when every rank built the model from one seed)
             broadcast_parameters(model)
         self.opt = ShardedAdamW(self.params, lr=learning_rate, weight_decay=weight_decay, overlap=False)
         # frozen decoder weights (projector / LoRA tuning): keep K-contiguous copies for the

@@ -259,6 +259,12 @@ class TensorParallelEngine(GenerationEngine):
                     # sized for a full cache of rows (larger packs take the library collective)
                     rows = min(max(self.l_max, self.PACK_ROWS), 16384)
                     self.twoshot = comm.TwoShotAllReduce(self.tp_group, dev, rows * self.H)
+                    # A rank's block waits for the same block of its peers.  Ranks with a GPU each
+                    # progress independently; ranks that SHARE one (the gloo-bootstrapped test and
+                    # rehearsal set-up) need all their blocks resident together, or the waiting
+                    # blocks of one rank keep the others' off the CUs until the waits give up.  There
+                    # the two-shot is kept to messages of at most 1536 blocks over all ranks.
+                    self._twoshot_cap = 1536 * 2048 if self._gloo else rows * self.H
                     torch.cuda.synchronize(dev)
                     dist.barrier(group=self.tp_group)      # every rank's buffers are mapped before the first push
                 else:
@@ -364,7 +370,7 @@ class TensorParallelEngine(GenerationEngine):
     # -------------------------------------------------------------- collectives
     def _reduce(self, t: torch.Tensor) -> torch.Tensor:
         if (self.twoshot is not None and t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() % 8 == 0
-                and self.twoshot.reduce(t)):
+                and t.numel() <= self._twoshot_cap and self.twoshot.reduce(t)):
             return t
         return _all_reduce(t, self.tp_group)
 
