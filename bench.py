@@ -290,6 +290,8 @@ def timed_decode(args, engine, embeds, batch: int, dist, dev):
     cold_ms = None
     if args.settle_steps > 0:
         start()
+        engine.decode_step(True)        # (captures the step's graph, outside every clock)
+        start()
         # the unsettled figure, for the record: the first steps after the prefill, as a run without the
         # settling phase would time them (they are the start of that phase, not additional work)
         n_cold = min(20, args.settle_steps)
