@@ -162,6 +162,12 @@ class SelfAttention(nn.Module):
     def forward(self, x, causal: bool = False, key_padding_mask: Optional[torch.Tensor] = None):
         b, s, e = x.shape
         qkv = F.linear(x, self.in_proj_weight, self.in_proj_bias)
+        if e // self.num_heads == 512 and qkv.is_cuda:
+            from ..ops import differentiable as diff
+            if diff.attention_d512_ok(qkv, self.num_heads):
+                o = diff.attention_d512(qkv, self.num_heads, causal, key_padding_mask,
+                                        self.dropout if self.training else 0.0)
+                return self.out_proj(o)
         q, k, v = qkv.view(b, s, 3, self.num_heads, e // self.num_heads).permute(2, 0, 3, 1, 4)
         mask = None
         if key_padding_mask is not None:      # True = padded key

@@ -115,6 +115,20 @@ def acceptance_rates(cos: torch.Tensor, thresholds=(0.80, 0.85, 0.90, 0.95)) -> 
     return {f"accept_{int(round(t * 100))}": float((cos > t).float().mean()) for t in thresholds}
 
 
+_BF16_COPIES = {}
+
+
+def _bf16_copy(w: torch.Tensor) -> torch.Tensor:
+    """A frozen matrix in bf16, converted once (keyed by storage and version)."""
+    if w.dtype == torch.bfloat16 and w.is_contiguous():
+        return w
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _BF16_COPIES.get("w")
+    if hit is None or hit[0] != key:
+        _BF16_COPIES["w"] = (key, w.detach().to(torch.bfloat16).contiguous())
+    return _BF16_COPIES["w"][1]
+
+
 def lora_distill_loss(pred_hidden: torch.Tensor, target_hidden: torch.Tensor,
                       lm_head_weight: torch.Tensor, cos_weight: float = 0.5,
                       ce_weight: float = 0.1) -> Dict[str, torch.Tensor]:
@@ -124,6 +138,21 @@ def lora_distill_loss(pred_hidden: torch.Tensor, target_hidden: torch.Tensor,
     t = target_hidden.float().reshape(-1, target_hidden.shape[-1])
     mse = F.mse_loss(p, t)
     cos = F.cosine_embedding_loss(p, t, torch.ones(p.shape[0], device=p.device))
+    from ..ops import differentiable as diff
+    if pred_hidden.is_cuda and pred_hidden.dtype == torch.bfloat16 and lm_head_weight.shape[1] % 64 == 0:
+        # token term on the in-tree kernels: target tokens from the GEMM's argmax epilogue, the loss from
+        # bf16 logits without an fp32 [rows, vocab] tensor (``ops.differentiable.linear_cross_entropy``)
+        wb = _bf16_copy(lm_head_weight)
+        ph = pred_hidden.reshape(-1, pred_hidden.shape[-1])
+        if diff.linear_cross_entropy_ok(ph, wb):
+            from ..ops import hip
+            with torch.no_grad():
+                pv, pi = hip.raw.linear_argmax_partials(target_hidden.reshape(-1, ph.shape[-1]).to(torch.bfloat16)
+                                                        .contiguous(), wb, None)
+                tgt_tok = pi.gather(1, pv.argmax(1, keepdim=True))[:, 0]
+            ce = diff.linear_cross_entropy(ph, wb, tgt_tok.long(), -100, None)
+            return {"total_loss": mse + cos_weight * cos + ce_weight * ce, "mse_loss": mse,
+                    "cos_loss": cos, "ce_loss": ce, "cos_sim": cosine_per_position(p, t).mean()}
     w = lm_head_weight.float()
     with torch.no_grad():
         tgt_tok = (t @ w.t()).argmax(-1)

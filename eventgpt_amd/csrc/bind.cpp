@@ -586,6 +586,145 @@ std::tuple<Tensor, Tensor> rmsnorm_bwd(const Tensor& x, const Tensor& w, const T
   return std::make_tuple(dx, dw);
 }
 
+// ---- training kernels of the hidden-state adapters (adapter_train.hip)
+// qkv [B, S, 3 * H * 512] packed in-projection -> (out [B, S, H * 512], probs [B, H, 64, 64])
+std::tuple<Tensor, Tensor> attn512_fwd(const Tensor& qkv, int64_t H, bool causal, const c10::optional<Tensor>& kpm,
+                                       double scale, double drop_p, int64_t seed, bool save_probs) {
+  check_bf16(qkv, "qkv");
+  TORCH_CHECK(qkv.dim() == 3 && qkv.is_contiguous() && H >= 1 && qkv.size(2) == 3 * H * 512 && qkv.size(1) >= 1 &&
+              qkv.size(1) <= 64 && drop_p >= 0 && drop_p < 1, "attn512_fwd: qkv [B, S <= 64, 3 * H * 512] contiguous bf16");
+  const int64_t B = qkv.size(0), S = qkv.size(1), E = H * 512;
+  const unsigned char* mask = nullptr;
+  if (kpm.has_value() && kpm->defined()) {
+    TORCH_CHECK(kpm->is_cuda() && kpm->is_contiguous() && kpm->numel() == B * S &&
+                (kpm->scalar_type() == at::kBool || kpm->scalar_type() == at::kByte), "attn512_fwd: kpm bool [B, S]");
+    mask = reinterpret_cast<const unsigned char*>(kpm->data_ptr());
+  }
+  Tensor out = at::empty({B, S, E}, qkv.options());
+  Tensor probs = save_probs ? at::empty({B, H, 64, 64}, qkv.options()) : at::empty({0}, qkv.options());
+  if (B > 0)
+    evgpt::launch_attn512_fwd(bptr(qkv), bptr(qkv) + E, bptr(qkv) + 2 * E, S * 3 * E, 3 * E, bptr_mut(out),
+                              save_probs ? bptr_mut(probs) : nullptr, mask, (int)B, (int)S, (int)H, causal ? 1 : 0,
+                              (float)scale, (float)drop_p, (unsigned long long)seed, cur_stream());
+  return {out, probs};
+}
+
+Tensor attn512_bwd(const Tensor& qkv, const Tensor& d_out, const Tensor& probs, int64_t H, double scale, double drop_p,
+                   int64_t seed) {
+  check_bf16(qkv, "qkv"); check_bf16(d_out, "d_out"); check_bf16(probs, "probs");
+  TORCH_CHECK(qkv.dim() == 3 && qkv.is_contiguous() && qkv.size(2) == 3 * H * 512 && qkv.size(1) <= 64, "attn512_bwd: qkv");
+  const int64_t B = qkv.size(0), S = qkv.size(1), E = H * 512;
+  TORCH_CHECK(d_out.is_contiguous() && d_out.numel() == B * S * E && probs.is_contiguous() &&
+              probs.numel() == B * H * 64 * 64, "attn512_bwd: d_out [B, S, H * 512], probs [B, H, 64, 64]");
+  Tensor dqkv = at::empty_like(qkv);
+  if (B > 0)
+    evgpt::launch_attn512_bwd(bptr(qkv), bptr(qkv) + E, bptr(qkv) + 2 * E, S * 3 * E, 3 * E, bptr(d_out), bptr(probs),
+                              bptr_mut(dqkv), bptr_mut(dqkv) + E, bptr_mut(dqkv) + 2 * E, (int)B, (int)S, (int)H,
+                              (float)scale, (float)drop_p, (unsigned long long)seed, cur_stream());
+  return dqkv;
+}
+
+// keep mask [B, H, 64, 64] (uint8) of the attention dropout for (drop_p, seed)
+Tensor attn512_mask(int64_t B, int64_t H, double drop_p, int64_t seed, const Tensor& like) {
+  Tensor out = at::empty({B, H, 64, 64}, like.options().dtype(at::kByte));
+  evgpt::launch_attn512_mask(out.data_ptr<uint8_t>(), out.numel(), (float)drop_p, (unsigned long long)seed, cur_stream());
+  return out;
+}
+
+static void check_ew(const Tensor& x, const char* what) {
+  check_bf16(x, what);
+  TORCH_CHECK(x.is_contiguous() && x.numel() % 8 == 0 && (reinterpret_cast<uintptr_t>(x.data_ptr()) & 15) == 0,
+              what, ": contiguous bf16, a multiple of 8 elements, 16-byte aligned");
+}
+Tensor gelu_fwd(const Tensor& x) {
+  check_ew(x, "gelu");
+  Tensor y = at::empty_like(x);
+  evgpt::launch_gelu(bptr(x), bptr_mut(y), x.numel(), cur_stream());
+  return y;
+}
+Tensor gelu_bwd(const Tensor& x, const Tensor& g) {
+  check_ew(x, "gelu_bwd x"); check_ew(g, "gelu_bwd grad");
+  TORCH_CHECK(g.numel() == x.numel());
+  Tensor dx = at::empty_like(x);
+  evgpt::launch_gelu_bwd(bptr(x), bptr(g), bptr_mut(dx), x.numel(), cur_stream());
+  return dx;
+}
+// y = keep ? x / (1 - p) : 0 with the keep mask a function of (seed, element index): the same call on the
+// incoming gradient is the backward
+Tensor dropout_fwd(const Tensor& x, double p, int64_t seed) {
+  check_ew(x, "dropout");
+  TORCH_CHECK(p >= 0 && p < 1);
+  Tensor y = at::empty_like(x);
+  evgpt::launch_dropout(bptr(x), bptr_mut(y), x.numel(), (float)p, (unsigned long long)seed, cur_stream());
+  return y;
+}
+
+// (dx, dw, db): fp32 parameter gradients when want_params, else empty tensors
+std::tuple<Tensor, Tensor, Tensor> layernorm_bwd(const Tensor& x, const Tensor& w, const Tensor& g, double eps,
+                                                 bool want_params) {
+  check_bf16(x, "x"); check_bf16(w, "weight"); check_bf16(g, "grad");
+  const int64_t H = x.size(-1), rows = x.numel() / H;
+  TORCH_CHECK(H % 8 == 0 && H <= 8192 && w.numel() == H && g.numel() == x.numel(),
+              "layernorm_bwd: hidden size must be a multiple of 8 up to 8192");
+  Tensor dx = at::empty_like(x);
+  auto f32 = x.options().dtype(at::kFloat);
+  Tensor pw, pb;
+  if (want_params && rows > 0) {
+    const int64_t nb = evgpt::layernorm_bwd_blocks((int)rows);
+    pw = at::empty({nb, H}, f32);
+    pb = at::empty({nb, H}, f32);
+  }
+  evgpt::launch_layernorm_bwd(bptr(x), bptr(w), bptr(g), bptr_mut(dx), pw.defined() ? pw.data_ptr<float>() : nullptr,
+                              pb.defined() ? pb.data_ptr<float>() : nullptr, (int)rows, (int)H, (float)eps, cur_stream());
+  Tensor dw = pw.defined() ? pw.sum(0) : at::zeros({want_params ? H : 0}, f32);
+  Tensor db = pb.defined() ? pb.sum(0) : at::zeros({want_params ? H : 0}, f32);
+  return std::make_tuple(dx, dw, db);
+}
+
+// ---- loss.hip
+// logits [M, V] bf16 (any row stride), labels int32 [M] -> (lse [M], loss rows [M], stat [2] = mean, 1 / count)
+std::tuple<Tensor, Tensor, Tensor> ce_fwd(const Tensor& logits, const Tensor& labels, int64_t ignore) {
+  check_bf16(logits, "logits"); check_i32(labels, "labels");
+  TORCH_CHECK(logits.dim() == 2 && logits.stride(1) == 1 && labels.numel() == logits.size(0) && logits.size(1) >= 1,
+              "ce_fwd: logits [M, V] with unit column stride, labels [M]");
+  const int64_t M = logits.size(0), V = logits.size(1);
+  auto f32 = logits.options().dtype(at::kFloat);
+  Tensor lse = at::empty({M}, f32), loss = at::empty({M}, f32), stat = at::zeros({2}, f32);
+  evgpt::launch_ce_fwd(bptr(logits), logits.stride(0), labels.data_ptr<int>(), lse.data_ptr<float>(),
+                       loss.data_ptr<float>(), stat.data_ptr<float>(), (int)M, (int)V, (int)ignore, cur_stream());
+  return {lse, loss, stat};
+}
+// d logits [M, round_up(V, 64)] (padding columns zero) for the upstream gradient `upstream` (device scalar)
+Tensor ce_bwd(const Tensor& logits, const Tensor& labels, const Tensor& lse, const Tensor& upstream, const Tensor& stat,
+              int64_t ignore) {
+  check_bf16(logits, "logits"); check_i32(labels, "labels"); check_f32(lse, "lse"); check_f32(upstream, "upstream");
+  check_f32(stat, "stat");
+  TORCH_CHECK(logits.dim() == 2 && logits.stride(1) == 1 && labels.numel() == logits.size(0) &&
+              lse.numel() == logits.size(0) && upstream.numel() >= 1 && stat.numel() >= 2, "ce_bwd: shapes");
+  const int64_t M = logits.size(0), V = logits.size(1), Vp = (V + 63) / 64 * 64;
+  Tensor d = at::empty({M, Vp}, logits.options());
+  evgpt::launch_ce_bwd(bptr(logits), logits.stride(0), labels.data_ptr<int>(), lse.data_ptr<float>(),
+                       upstream.data_ptr<float>(), stat.data_ptr<float>(), bptr_mut(d), Vp, (int)M, (int)V, (int)ignore,
+                       cur_stream());
+  return d;
+}
+Tensor rows_gather(const Tensor& src, const Tensor& idx) {
+  check_bf16(src, "src"); check_i32(idx, "idx");
+  TORCH_CHECK(src.dim() == 2 && src.is_contiguous() && src.size(1) % 8 == 0 && src.size(0) >= 1, "rows_gather: src [R, K % 8 == 0]");
+  Tensor out = at::empty({idx.numel(), src.size(1)}, src.options());
+  evgpt::launch_rows_gather(bptr(src), idx.data_ptr<int>(), bptr_mut(out), (int)idx.numel(), (int)src.size(1),
+                            (int)src.size(0), cur_stream());
+  return out;
+}
+// [R, K] with row idx[i] = g[i] and zeros elsewhere; idx ascending and unique
+Tensor rows_scatter(const Tensor& g, const Tensor& idx, int64_t R) {
+  check_bf16(g, "g"); check_i32(idx, "idx");
+  TORCH_CHECK(g.dim() == 2 && g.is_contiguous() && g.size(1) % 8 == 0 && g.size(0) == idx.numel() && R >= 0, "rows_scatter: g [n, K % 8 == 0]");
+  Tensor out = at::empty({R, g.size(1)}, g.options());
+  evgpt::launch_rows_scatter(bptr(g), idx.data_ptr<int>(), bptr_mut(out), (int)idx.numel(), (int)g.size(1), (int)R, cur_stream());
+  return out;
+}
+
 Tensor swiglu_bwd(const Tensor& gate_up, const Tensor& gh) {
   check_bf16(gate_up, "gate_up"); check_bf16(gh, "grad");
   const int64_t I2 = gate_up.size(-1), M = gate_up.numel() / I2;
@@ -1131,6 +1270,17 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("decode_gemv_residual(Tensor w, Tensor xin, Tensor(a!) y) -> ()", &decode_gemv_residual);
   m.def("rmsnorm_bwd(Tensor x, Tensor weight, Tensor grad, float eps, bool want_dw=False) -> (Tensor, Tensor)", &rmsnorm_bwd);
   m.def("swiglu_bwd(Tensor gate_up, Tensor grad) -> Tensor", &swiglu_bwd);
+  m.def("ce_fwd(Tensor logits, Tensor labels, int ignore) -> (Tensor, Tensor, Tensor)", &ce_fwd);
+  m.def("ce_bwd(Tensor logits, Tensor labels, Tensor lse, Tensor upstream, Tensor stat, int ignore) -> Tensor", &ce_bwd);
+  m.def("rows_gather(Tensor src, Tensor idx) -> Tensor", &rows_gather);
+  m.def("rows_scatter(Tensor g, Tensor idx, int R) -> Tensor", &rows_scatter);
+  m.def("attn512_fwd(Tensor qkv, int H, bool causal, Tensor? kpm, float scale, float drop_p, int seed, bool save_probs) -> (Tensor, Tensor)", &attn512_fwd);
+  m.def("attn512_bwd(Tensor qkv, Tensor d_out, Tensor probs, int H, float scale, float drop_p, int seed) -> Tensor", &attn512_bwd);
+  m.def("attn512_mask(int B, int H, float drop_p, int seed, Tensor like) -> Tensor", &attn512_mask);
+  m.def("gelu_fwd(Tensor x) -> Tensor", &gelu_fwd);
+  m.def("gelu_bwd(Tensor x, Tensor grad) -> Tensor", &gelu_bwd);
+  m.def("dropout_fwd(Tensor x, float p, int seed) -> Tensor", &dropout_fwd);
+  m.def("layernorm_bwd(Tensor x, Tensor weight, Tensor grad, float eps, bool want_params=True) -> (Tensor, Tensor, Tensor)", &layernorm_bwd);
   m.def("sumsq_accumulate(Tensor x, Tensor(a!) acc) -> ()", &sumsq_accumulate);
   m.def("fused_adamw(Tensor grad, Tensor(a!) master, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor(d!) param_out, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float clip, Tensor? clip_dev=None) -> ()", &fused_adamw);
   m.def("w4_dequant(Tensor packed, Tensor absmax, Tensor code, Tensor(a!)? out=None) -> Tensor", &w4_dequant);

@@ -40,6 +40,35 @@ void launch_rmsnorm_bwd(const bf16_t* x, const bf16_t* w, const bf16_t* g, bf16_
                         int H, float eps, hipStream_t st);
 void launch_swiglu_bwd(const bf16_t* gate_up, const bf16_t* gh, bf16_t* dgu, long long M, int I, hipStream_t st);
 
+// ---- adapter_train.hip (training of the hidden-state adapters)
+// q / k / v: element (b, s, h, d) at b*sb + s*ss + h*512 + d (e.g. the thirds of a packed in-projection);
+// S <= 64; probs [B][H][64][64] bf16 (softmax before dropout; may be null in the forward); kpm [B][S]
+// bytes, 1 = padded key, or null; drop_p in [0, 1); the dropout mask is a function of (seed, b, h, row, key)
+void launch_attn512_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, long long sb, long long ss, bf16_t* out,
+                        bf16_t* probs, const unsigned char* kpm, int B, int S, int H, int causal, float scale,
+                        float drop_p, unsigned long long seed, hipStream_t st);
+void launch_attn512_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, long long sb, long long ss,
+                        const bf16_t* d_out, const bf16_t* probs, bf16_t* dq, bf16_t* dk, bf16_t* dv, int B, int S,
+                        int H, float scale, float drop_p, unsigned long long seed, hipStream_t st);
+void launch_attn512_mask(unsigned char* out, long long n, float drop_p, unsigned long long seed, hipStream_t st);
+void launch_gelu(const bf16_t* x, bf16_t* y, long long n, hipStream_t st);                       // n % 8 == 0
+void launch_gelu_bwd(const bf16_t* x, const bf16_t* g, bf16_t* dx, long long n, hipStream_t st);
+void launch_dropout(const bf16_t* x, bf16_t* y, long long n, float p, unsigned long long seed, hipStream_t st);
+int layernorm_bwd_blocks(int rows);    // rows of the [blocks][H] fp32 dw / db partial buffers
+void launch_layernorm_bwd(const bf16_t* x, const bf16_t* w, const bf16_t* g, bf16_t* dx, float* dw, float* db,
+                          int rows, int H, float eps, hipStream_t st);
+
+// ---- loss.hip (token cross-entropy on bf16 logits; gather / scatter of the supervised rows)
+// logits [M][ld] bf16, labels [M] (ignore, or anything outside [0, V), counts as unsupervised);
+// lse / loss [M] fp32; stat [2] fp32 = {mean loss over supervised rows, 1 / their count}
+void launch_ce_fwd(const bf16_t* logits, long long ld, const int* labels, float* lse, float* loss, float* stat, int M,
+                   int V, int ignore, hipStream_t st);
+// dlogits [M][ldd] (ldd even, >= V; columns >= V are zeroed) = (softmax - onehot) * upstream[0] * stat[1]
+void launch_ce_bwd(const bf16_t* logits, long long ld, const int* labels, const float* lse, const float* upstream,
+                   const float* stat, bf16_t* dlogits, long long ldd, int M, int V, int ignore, hipStream_t st);
+void launch_rows_gather(const bf16_t* src, const int* idx, bf16_t* out, int n, int K, int n_src, hipStream_t st);
+void launch_rows_scatter(const bf16_t* g, const int* idx, bf16_t* out, int n, int K, int R, hipStream_t st);
+
 // ---- optim.hip
 // clip_dev (optional): a device scalar multiplied into `clip` by the kernel itself, so a clip factor
 // derived from the global gradient norm never has to visit the host

@@ -430,7 +430,9 @@ class EventChatModel(nn.Module):
         if had_labels:
             lab_h = labels.detach().cpu()
             flat = torch.cat([lab_h.reshape(-1), lab_h.new_full((1,), IGNORE_INDEX)])
-            out_labels = flat[lab_src.clamp(min=-1)].reshape(bsz, max_len).to(labels.device)
+            host_labels = flat[lab_src.clamp(min=-1)].reshape(bsz, max_len)
+            out_labels = host_labels.to(labels.device)
+            out_labels.host_copy = host_labels      # the loss selects the supervised rows on the host
         out_pos = (torch.arange(max_len)[None].expand(bsz, max_len) * out_mask).to(input_ids.device)
         return (None,
                 out_pos if had_pos else None,
@@ -451,7 +453,16 @@ class EventChatModel(nn.Module):
                          attention_mask=attention_mask, position_ids=position_ids,
                          past_key_values=past_key_values, inputs_embeds=inputs_embeds,
                          use_cache=use_cache, output_hidden_states=output_hidden_states)
-        logits = self.lm_head(out.last_hidden_state)
+        h = out.last_hidden_state
+        from ..ops import differentiable as diff
+        if labels is not None and h.requires_grad and diff.linear_cross_entropy_ok(h, self.lm_head.weight):
+            # training step on the GPU: the LM head runs on the supervised rows only and the loss never
+            # materialises fp32 logits (``ops.differentiable.linear_cross_entropy``); ``logits`` is None
+            host = getattr(labels, "host_copy", None)
+            loss = diff.linear_cross_entropy(h[:, :-1], self.lm_head.weight, labels[:, 1:], IGNORE_INDEX,
+                                             None if host is None else host[:, 1:])
+            return CausalLMOutput(None, out.past_key_values, out.hidden_states, loss)
+        logits = self.lm_head(h)
         loss = None
         if labels is not None:
             shift_logits = logits[:, :-1].float().reshape(-1, logits.shape[-1])

@@ -109,8 +109,119 @@ def add_rmsnorm(x, residual, weight, eps: float = 1e-6) -> Tuple[torch.Tensor, t
     return rmsnorm(r, weight, eps), r
 
 
+class _LayerNorm(torch.autograd.Function):
+    """LayerNorm on bf16 activations: the inference kernel forward, one backward kernel
+    (``csrc/kernels/adapter_train.hip``).  Weight and bias may be fp32 parameters (training under bf16
+    autocast): they are rounded to bf16 for the kernels and receive fp32 gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        xc = x.contiguous()
+        wb = weight.detach().to(torch.bfloat16).contiguous()
+        bb = None if bias is None else bias.detach().to(torch.bfloat16).contiguous()
+        ctx.save_for_backward(xc, wb)
+        ctx.eps, ctx.has_bias = eps, bias is not None
+        ctx.pdtype = (weight.dtype, None if bias is None else bias.dtype)
+        return _raw().layernorm(xc, wb, bb, eps, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wb = ctx.saved_tensors
+        want = bool(ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]))
+        dx, dw, db = _raw().layernorm_bwd(x, wb, g.contiguous(), ctx.eps, want)
+        return (dx, dw.to(ctx.pdtype[0]).view_as(wb) if ctx.needs_input_grad[1] else None,
+                db.to(ctx.pdtype[1]).view_as(wb) if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None)
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xc = x.contiguous()
+        ctx.save_for_backward(xc)
+        return _raw().gelu_fwd(xc)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return _raw().gelu_bwd(x, g.contiguous())
+
+
+class _Dropout(torch.autograd.Function):
+    """Inverted dropout whose keep mask is a counter-based hash of (seed, element index): nothing is
+    stored for the backward, which re-applies the same mask to the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return _raw().dropout_fwd(x.contiguous(), p, seed)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _raw().dropout_fwd(g.contiguous(), ctx.p, ctx.seed), None, None
+
+
+def next_seed() -> int:
+    """A fresh seed for the counter-based dropout masks, drawn from torch's CPU generator (so
+    ``torch.manual_seed`` makes a run repeatable)."""
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+
+def _ew_ok(x) -> bool:
+    return _fused(x) and x.numel() > 0 and x.numel() % 8 == 0
+
+
 def layernorm(x, weight, bias, eps: float = 1e-5):
-    return F.layer_norm(x, (x.shape[-1],), weight.to(x.dtype), None if bias is None else bias.to(x.dtype), eps)
+    h = x.shape[-1]
+    if (_fused(x) and weight is not None and weight.is_cuda and weight.numel() == h and h % 8 == 0 and h <= 8192
+            and x.numel() > 0 and (bias is None or bias.is_cuda)):
+        return _LayerNorm.apply(x, weight, bias, eps)
+    return F.layer_norm(x, (h,), None if weight is None else weight.to(x.dtype),
+                        None if bias is None else bias.to(x.dtype), eps)
+
+
+def gelu(x):
+    return _Gelu.apply(x) if _ew_ok(x) else F.gelu(x)
+
+
+def dropout(x, p: float, training: bool = True):
+    if not training or p <= 0.0:
+        return x
+    if _ew_ok(x) and p < 1.0:
+        return _Dropout.apply(x, float(p), next_seed())
+    return F.dropout(x, p, True)
+
+
+class _AttnD512(torch.autograd.Function):
+    """Self-attention with head_dim 512 over a packed in-projection ``[B, S <= 64, 3 * H * 512]``
+    (``csrc/kernels/adapter_train.hip``): the forward keeps the 64 x 64 probabilities of every
+    head, the backward returns the gradient of the packed projection in one tensor."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, causal, kpm, scale, drop_p, seed):
+        qc = qkv.contiguous()
+        out, probs = _raw().attn512_fwd(qc, heads, bool(causal), kpm, float(scale), float(drop_p), int(seed), True)
+        ctx.save_for_backward(qc, probs)
+        ctx.args = (heads, float(scale), float(drop_p), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, probs = ctx.saved_tensors
+        heads, scale, drop_p, seed = ctx.args
+        return _raw().attn512_bwd(qkv, g.contiguous(), probs, heads, scale, drop_p, seed), None, None, None, None, None, None
+
+
+def attention_d512_ok(qkv, heads: int) -> bool:
+    return (_fused(qkv) and qkv.dim() == 3 and qkv.shape[-1] == 3 * heads * 512 and 1 <= qkv.shape[1] <= 64
+            and qkv.shape[0] >= 1)
+
+
+def attention_d512(qkv, heads: int, causal: bool = False, key_padding_mask=None, dropout_p: float = 0.0):
+    """``[B, S, 3 * heads * 512]`` packed q | k | v (``nn.MultiheadAttention``'s in-projection layout)
+    -> ``[B, S, heads * 512]``.  ``key_padding_mask``: bool ``[B, S]``, True = padded key."""
+    kpm = None if key_padding_mask is None else key_padding_mask.to(torch.bool).contiguous()
+    seed = next_seed() if dropout_p > 0 else 0
+    return _AttnD512.apply(qkv, heads, causal, kpm, 1.0 / math.sqrt(512), dropout_p, seed)
 
 
 def _round64(n: int) -> int:
@@ -288,6 +399,85 @@ def linear(x, weight, bias=None, act: Optional[str] = None, residual=None):
         y = F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
     y = _ACTS[act](y)
     return y if residual is None else y + residual
+
+
+class _GatherRows(torch.autograd.Function):
+    """``x[idx]`` for ascending unique row indices; the backward writes the whole ``[R, K]`` gradient in
+    one launch (the gathered rows, zeros elsewhere) instead of a zero fill plus an indexed accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.rows = x.shape[0]
+        return _raw().rows_gather(x.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return _raw().rows_scatter(g.contiguous(), idx, ctx.rows), None
+
+
+class _LinearCrossEntropy(torch.autograd.Function):
+    """Mean token cross-entropy of ``x W^T`` against ``labels`` (``csrc/kernels/loss.hip``): bf16 logits
+    from the in-tree GEMM, log-sum-exp and loss per row in one pass, and in the backward the logits'
+    gradient written once, in bf16, into a row-padded buffer that the dgrad / wgrad GEMMs read.  No fp32
+    copy of the logits, no softmax tensor, and the upstream gradient never visits the host."""
+
+    @staticmethod
+    def forward(ctx, x, weight, labels, ignore):
+        from . import hip
+        logits = hip.linear(x, weight)                           # [M, V] bf16
+        lab = labels.to(torch.int32).contiguous()
+        lse, _, stat = _raw().ce_fwd(logits, lab, ignore)
+        ctx.save_for_backward(x, weight, logits, lab, lse, stat)
+        ctx.ignore = ignore
+        return stat[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, logits, lab, lse, stat = ctx.saved_tensors
+        v, k = weight.shape
+        up = g.reshape(1).to(torch.float32)
+        d = _raw().ce_bwd(logits, lab, lse, up, stat, ctx.ignore)          # [M, round_up(V, 64)], zero padding
+        vp = d.shape[1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = _transposed_for_dgrad(weight)
+            if wt is not None and v % 8 == 0:
+                from . import hip
+                dx = hip.linear(d[:, :v].contiguous() if vp != v else d, wt)
+            else:
+                # contraction over the vocabulary: W's rows; rows past V read as zeros, d's padding is zero
+                dx = _raw().linear_t(d, weight.contiguous(), False, True, None, None, 0, False, vp)
+        if ctx.needs_input_grad[1]:
+            full = _raw().linear_t(d, x, True, True, None, None, 0, False, _round64(x.shape[0]))   # [Vp, K]
+            dw = full[:v]
+        return dx, dw, None, None
+
+
+def linear_cross_entropy_ok(x, weight) -> bool:
+    return (_fused(x, weight) and weight.dim() == 2 and x.shape[-1] == weight.shape[1] and weight.shape[1] % 8 == 0
+            and weight.shape[0] >= 8 and weight.shape[0] * weight.shape[1] < (1 << 30))
+
+
+def linear_cross_entropy(hidden, weight, labels, ignore_index: int = -100, host_labels=None):
+    """``cross_entropy(hidden @ weight^T, labels)`` (mean over the labels that are not ``ignore_index``)
+    with the projection restricted to the supervised rows.  ``hidden [.., K]``, ``labels [..]``;
+    ``host_labels``: a CPU copy of ``labels`` if the caller has one (the row selection is host
+    arithmetic; without it the labels are read back once)."""
+    k = hidden.shape[-1]
+    x = hidden.reshape(-1, k)
+    lab = labels.reshape(-1)
+    lab_h = (host_labels if host_labels is not None else lab.detach().cpu()).reshape(-1)
+    rows = (lab_h != ignore_index).nonzero().reshape(-1)
+    if not linear_cross_entropy_ok(x, weight) or k % 8 or rows.numel() == 0:
+        sel = rows.to(x.device)
+        return F.cross_entropy(F.linear(x[sel], weight.to(x.dtype)).float(), lab[sel], ignore_index=ignore_index) \
+            if rows.numel() else x.sum() * 0.0
+    idx = rows.to(torch.int32).to(x.device, non_blocking=True)
+    xs = _GatherRows.apply(x, idx) if rows.numel() < x.shape[0] else x.contiguous()
+    ls = lab_h[rows].to(torch.int32).to(x.device, non_blocking=True)
+    return _LinearCrossEntropy.apply(xs, weight, ls, int(ignore_index))
 
 
 class _LowRank(torch.autograd.Function):
