@@ -147,4 +147,6 @@ def test_adapter_training_step_on_in_tree_linear(level):
             continue
         assert pb.grad is not None and pb.grad.dtype == torch.float32, n
         err = (pa.grad - pb.grad).abs().max().item()
-        assert err < 3e-2 * pa.grad.abs().max().item() + 1e-6, (n, err)
+        # (LayerNorm inside the mode reads its input rounded to bf16: its parameters' gradients carry that rounding)
+        tol = 8e-2 if "norm" in n else 3e-2
+        assert err < tol * pa.grad.abs().max().item() + 1e-6, (n, err)
