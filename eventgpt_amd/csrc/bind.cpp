@@ -683,7 +683,14 @@ std::tuple<Tensor, Tensor, Tensor> layernorm_bwd(const Tensor& x, const Tensor& 
 
 // ---- loss.hip
 // logits [M, V] bf16 (any row stride), labels int32 [M] -> (lse [M], loss rows [M], stat [2] = mean, 1 / count)
-std::tuple<Tensor, Tensor, Tensor> ce_fwd(const Tensor& logits, const Tensor& labels, int64_t ignore) {
+static const float* row_weights(const c10::optional<Tensor>& w, int64_t M) {
+  if (!w.has_value() || !w->defined()) return nullptr;
+  check_f32(*w, "row_weight");
+  TORCH_CHECK(w->numel() == M, "row_weight: one weight per row");
+  return w->data_ptr<float>();
+}
+std::tuple<Tensor, Tensor, Tensor> ce_fwd(const Tensor& logits, const Tensor& labels, int64_t ignore,
+                                          const c10::optional<Tensor>& row_weight) {
   check_bf16(logits, "logits"); check_i32(labels, "labels");
   TORCH_CHECK(logits.dim() == 2 && logits.stride(1) == 1 && labels.numel() == logits.size(0) && logits.size(1) >= 1,
               "ce_fwd: logits [M, V] with unit column stride, labels [M]");
@@ -691,12 +698,13 @@ std::tuple<Tensor, Tensor, Tensor> ce_fwd(const Tensor& logits, const Tensor& la
   auto f32 = logits.options().dtype(at::kFloat);
   Tensor lse = at::empty({M}, f32), loss = at::empty({M}, f32), stat = at::zeros({2}, f32);
   evgpt::launch_ce_fwd(bptr(logits), logits.stride(0), labels.data_ptr<int>(), lse.data_ptr<float>(),
-                       loss.data_ptr<float>(), stat.data_ptr<float>(), (int)M, (int)V, (int)ignore, cur_stream());
+                       loss.data_ptr<float>(), stat.data_ptr<float>(), (int)M, (int)V, (int)ignore, cur_stream(),
+                       row_weights(row_weight, M));
   return {lse, loss, stat};
 }
 // d logits [M, round_up(V, 64)] (padding columns zero) for the upstream gradient `upstream` (device scalar)
 Tensor ce_bwd(const Tensor& logits, const Tensor& labels, const Tensor& lse, const Tensor& upstream, const Tensor& stat,
-              int64_t ignore) {
+              int64_t ignore, const c10::optional<Tensor>& row_weight) {
   check_bf16(logits, "logits"); check_i32(labels, "labels"); check_f32(lse, "lse"); check_f32(upstream, "upstream");
   check_f32(stat, "stat");
   TORCH_CHECK(logits.dim() == 2 && logits.stride(1) == 1 && labels.numel() == logits.size(0) &&
@@ -705,7 +713,7 @@ Tensor ce_bwd(const Tensor& logits, const Tensor& labels, const Tensor& lse, con
   Tensor d = at::empty({M, Vp}, logits.options());
   evgpt::launch_ce_bwd(bptr(logits), logits.stride(0), labels.data_ptr<int>(), lse.data_ptr<float>(),
                        upstream.data_ptr<float>(), stat.data_ptr<float>(), bptr_mut(d), Vp, (int)M, (int)V, (int)ignore,
-                       cur_stream());
+                       cur_stream(), row_weights(row_weight, M));
   return d;
 }
 Tensor rows_gather(const Tensor& src, const Tensor& idx) {
@@ -1270,8 +1278,8 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("decode_gemv_residual(Tensor w, Tensor xin, Tensor(a!) y) -> ()", &decode_gemv_residual);
   m.def("rmsnorm_bwd(Tensor x, Tensor weight, Tensor grad, float eps, bool want_dw=False) -> (Tensor, Tensor)", &rmsnorm_bwd);
   m.def("swiglu_bwd(Tensor gate_up, Tensor grad) -> Tensor", &swiglu_bwd);
-  m.def("ce_fwd(Tensor logits, Tensor labels, int ignore) -> (Tensor, Tensor, Tensor)", &ce_fwd);
-  m.def("ce_bwd(Tensor logits, Tensor labels, Tensor lse, Tensor upstream, Tensor stat, int ignore) -> Tensor", &ce_bwd);
+  m.def("ce_fwd(Tensor logits, Tensor labels, int ignore, Tensor? row_weight=None) -> (Tensor, Tensor, Tensor)", &ce_fwd);
+  m.def("ce_bwd(Tensor logits, Tensor labels, Tensor lse, Tensor upstream, Tensor stat, int ignore, Tensor? row_weight=None) -> Tensor", &ce_bwd);
   m.def("rows_gather(Tensor src, Tensor idx) -> Tensor", &rows_gather);
   m.def("rows_scatter(Tensor g, Tensor idx, int R) -> Tensor", &rows_scatter);
   m.def("attn512_fwd(Tensor qkv, int H, bool causal, Tensor? kpm, float scale, float drop_p, int seed, bool save_probs) -> (Tensor, Tensor)", &attn512_fwd);

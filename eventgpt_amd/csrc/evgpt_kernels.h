@@ -60,12 +60,14 @@ void launch_layernorm_bwd(const bf16_t* x, const bf16_t* w, const bf16_t* g, bf1
 
 // ---- loss.hip (token cross-entropy on bf16 logits; gather / scatter of the supervised rows)
 // logits [M][ld] bf16, labels [M] (ignore, or anything outside [0, V), counts as unsupervised);
-// lse / loss [M] fp32; stat [2] fp32 = {mean loss over supervised rows, 1 / their count}
+// lse / loss [M] fp32; stat [2] fp32 = {mean loss over supervised rows, 1 / their count}, or with row
+// weights wrow [M] = {sum_i w_i loss_i, 1}
 void launch_ce_fwd(const bf16_t* logits, long long ld, const int* labels, float* lse, float* loss, float* stat, int M,
-                   int V, int ignore, hipStream_t st);
-// dlogits [M][ldd] (ldd even, >= V; columns >= V are zeroed) = (softmax - onehot) * upstream[0] * stat[1]
+                   int V, int ignore, hipStream_t st, const float* wrow = nullptr);
+// dlogits [M][ldd] (ldd even, >= V; columns >= V are zeroed) = (softmax - onehot) * upstream[0] * stat[1] (* wrow[i])
 void launch_ce_bwd(const bf16_t* logits, long long ld, const int* labels, const float* lse, const float* upstream,
-                   const float* stat, bf16_t* dlogits, long long ldd, int M, int V, int ignore, hipStream_t st);
+                   const float* stat, bf16_t* dlogits, long long ldd, int M, int V, int ignore, hipStream_t st,
+                   const float* wrow = nullptr);
 void launch_rows_gather(const bf16_t* src, const int* idx, bf16_t* out, int n, int K, int n_src, hipStream_t st);
 void launch_rows_scatter(const bf16_t* g, const int* idx, bf16_t* out, int n, int K, int R, hipStream_t st);
 

@@ -50,19 +50,21 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
-// stat[0] = mean loss over the counted rows, stat[1] = 1 / max(count, 1); one block
+// stat[0] = mean loss over the counted rows, stat[1] = 1 / max(count, 1); with row weights
+// stat[0] = sum_i w_i loss_i and stat[1] = 1 (the weights carry the normalisation); one block
 __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ loss, const int* __restrict__ labels,
-                                                        int M, int V, int ignore, float* __restrict__ stat) {
+                                                        const float* __restrict__ wrow, int M, int V, int ignore,
+                                                        float* __restrict__ stat) {
   __shared__ float red[16];
   float s = 0.f, c = 0.f;
   for (int i = threadIdx.x; i < M; i += 256) {
     const int lab = labels[i];
-    if (lab != ignore && lab >= 0 && lab < V) { s += loss[i]; c += 1.f; }
+    if (lab != ignore && lab >= 0 && lab < V) { s += wrow ? loss[i] * wrow[i] : loss[i]; c += 1.f; }
   }
   s = block_sum(s, red);
   c = block_sum(c, red);
   if (threadIdx.x == 0) {
-    const float inv = 1.f / fmaxf(c, 1.f);
+    const float inv = wrow ? 1.f : 1.f / fmaxf(c, 1.f);
     stat[0] = s * inv;
     stat[1] = inv;
   }
@@ -71,11 +73,12 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const bf16_t* __restrict__ logits, long long ld,
                                                      const int* __restrict__ labels, const float* __restrict__ lse,
                                                      const float* __restrict__ upstream, const float* __restrict__ stat,
-                                                     bf16_t* __restrict__ dlogits, long long ldd, int V, int ignore) {
+                                                     const float* __restrict__ wrow, bf16_t* __restrict__ dlogits,
+                                                     long long ldd, int V, int ignore) {
   const int row = blockIdx.x, tid = threadIdx.x;
   const int lab = labels[row];
   const bool live = !(lab == ignore || lab < 0 || lab >= V);
-  const float scale = live ? upstream[0] * stat[1] : 0.f;
+  const float scale = live ? upstream[0] * stat[1] * (wrow ? wrow[row] : 1.f) : 0.f;
   const float l = lse[row];
   const bf16_t* lr = logits + row * ld;
   unsigned int* dr = reinterpret_cast<unsigned int*>(dlogits + row * ldd);    // ldd is even: pairs are aligned
@@ -92,16 +95,17 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const bf16_t* __restrict__ 
 }
 
 void launch_ce_fwd(const bf16_t* logits, long long ld, const int* labels, float* lse, float* loss, float* stat, int M,
-                   int V, int ignore, hipStream_t st) {
+                   int V, int ignore, hipStream_t st, const float* wrow) {
   if (M <= 0) return;
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(M), dim3(256), 0, st, logits, ld, labels, lse, loss, V, ignore);
-  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, st, loss, labels, M, V, ignore, stat);
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, st, loss, labels, wrow, M, V, ignore, stat);
 }
 void launch_ce_bwd(const bf16_t* logits, long long ld, const int* labels, const float* lse, const float* upstream,
-                   const float* stat, bf16_t* dlogits, long long ldd, int M, int V, int ignore, hipStream_t st) {
+                   const float* stat, bf16_t* dlogits, long long ldd, int M, int V, int ignore, hipStream_t st,
+                   const float* wrow) {
   if (M <= 0) return;
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3(M), dim3(256), 0, st, logits, ld, labels, lse, upstream, stat, dlogits, ldd,
-                     V, ignore);
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(M), dim3(256), 0, st, logits, ld, labels, lse, upstream, stat, wrow, dlogits,
+                     ldd, V, ignore);
 }
 
 // out[i] = src[idx[i]] (rows of K bf16, K % 8 == 0)

@@ -379,6 +379,16 @@ class EventChatModel(nn.Module):
         if isinstance(event_tensors, (list, tuple)):
             samples = event_tensors if all(isinstance(s, (list, tuple)) for s in event_tensors) \
                 else [event_tensors]
+            t = len(samples[0])
+            if len(samples) > 1 and torch.is_grad_enabled() and all(len(s) == t for s in samples):
+                # a training batch: every sample's frames through the tower and the projector together
+                # (B x T x 577 rows in one set of GEMMs), pooled per sample
+                batch = torch.stack([f.to(self.device) for s in samples for f in s])
+                feats = self.visval_encode(batch)
+                if hasattr(self.get_model(), "feature_adaptor"):
+                    feats = self.get_model().feature_adaptor(feats)
+                feats = feats.view(len(samples), t, *feats.shape[1:])
+                return torch.stack([get_spatio_temporal_features(feats[i]) for i in range(len(samples))])
             return torch.stack([self.encode_event_frames(s) for s in samples])
         # a plain tensor batch: projector output only, no adaptor / pooling
         return self.visval_encode(event_tensors)
@@ -443,8 +453,14 @@ class EventChatModel(nn.Module):
     def forward(self, input_ids=None, attention_mask=None, position_ids=None,
                 past_key_values=None, inputs_embeds=None, labels=None, use_cache=False,
                 output_hidden_states=False, event_tensors=None, event_image_sizes=None,
-                event_features=None, already_adapted=False, return_dict=True):
+                event_features=None, already_adapted=False, return_dict=True,
+                loss_reduction: str = "token_mean"):
+        """``loss_reduction``: ``"token_mean"`` (mean over every supervised token of the batch, the HF
+        convention) or ``"sequence_mean"`` (mean over sequences of each sequence's token mean: a batch
+        of B samples then has the loss -- and gradients -- of B single-sample steps averaged)."""
+        spliced = False
         if inputs_embeds is None and (event_tensors is not None or event_features is not None):
+            spliced = True
             (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds,
              labels) = self.prepare_inputs_labels_for_multimodal(
                 input_ids, position_ids, attention_mask, past_key_values, labels,
@@ -452,7 +468,9 @@ class EventChatModel(nn.Module):
         out = self.model(input_ids=input_ids if inputs_embeds is None else None,
                          attention_mask=attention_mask, position_ids=position_ids,
                          past_key_values=past_key_values, inputs_embeds=inputs_embeds,
-                         use_cache=use_cache, output_hidden_states=output_hidden_states)
+                         use_cache=use_cache, output_hidden_states=output_hidden_states,
+                         # the splice above right-pads (tokens masked out on entry are dropped first)
+                         right_padded=spliced and labels is not None and not use_cache)
         h = out.last_hidden_state
         from ..ops import differentiable as diff
         if labels is not None and h.requires_grad and diff.linear_cross_entropy_ok(h, self.lm_head.weight):
@@ -460,15 +478,22 @@ class EventChatModel(nn.Module):
             # materialises fp32 logits (``ops.differentiable.linear_cross_entropy``); ``logits`` is None
             host = getattr(labels, "host_copy", None)
             loss = diff.linear_cross_entropy(h[:, :-1], self.lm_head.weight, labels[:, 1:], IGNORE_INDEX,
-                                             None if host is None else host[:, 1:])
+                                             None if host is None else host[:, 1:],
+                                             per_sequence_mean=loss_reduction == "sequence_mean")
             return CausalLMOutput(None, out.past_key_values, out.hidden_states, loss)
         logits = self.lm_head(h)
         loss = None
         if labels is not None:
             shift_logits = logits[:, :-1].float().reshape(-1, logits.shape[-1])
             shift_labels = labels[:, 1:].reshape(-1)
-            loss = torch.nn.functional.cross_entropy(shift_logits, shift_labels,
-                                                     ignore_index=IGNORE_INDEX)
+            if loss_reduction == "sequence_mean":
+                tok = torch.nn.functional.cross_entropy(shift_logits, shift_labels, ignore_index=IGNORE_INDEX,
+                                                        reduction="none").view(labels.shape[0], -1)
+                n = (labels[:, 1:] != IGNORE_INDEX).sum(1)
+                loss = (tok.sum(1) / n.clamp(min=1))[n > 0].mean()
+            else:
+                loss = torch.nn.functional.cross_entropy(shift_logits, shift_labels,
+                                                         ignore_index=IGNORE_INDEX)
         return CausalLMOutput(logits, out.past_key_values, out.hidden_states, loss)
 
     # ----------------------------------------------------------------- generate

@@ -212,7 +212,12 @@ class LlamaModel(nn.Module):
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None,
                 past_key_values=None, inputs_embeds=None, use_cache=False,
-                output_hidden_states=False, return_dict=True):
+                output_hidden_states=False, return_dict=True, right_padded: bool = False):
+        """``right_padded``: the caller vouches that ``attention_mask`` only marks padding at the END of
+        each sequence.  Without a cache, causal attention then needs no key mask at all -- a real
+        position never looks at a later one -- so batches of unequal length stay on the fused
+        attention kernels (rows at padded positions hold meaningless values; their labels are
+        ignored and they receive no gradient)."""
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("pass exactly one of input_ids / inputs_embeds")
         x = self.embed_tokens(input_ids) if inputs_embeds is None else inputs_embeds
@@ -223,7 +228,7 @@ class LlamaModel(nn.Module):
         elif position_ids.ndim == 1:
             position_ids = position_ids[None].expand(b, s)
         pad_mask = None
-        if attention_mask is not None:
+        if attention_mask is not None and not (right_padded and past_len == 0):
             am = attention_mask.bool()
             if not bool(am.all()):
                 pad_mask = am

@@ -424,21 +424,21 @@ class _LinearCrossEntropy(torch.autograd.Function):
     copy of the logits, no softmax tensor, and the upstream gradient never visits the host."""
 
     @staticmethod
-    def forward(ctx, x, weight, labels, ignore):
+    def forward(ctx, x, weight, labels, ignore, row_weight):
         from . import hip
         logits = hip.linear(x, weight)                           # [M, V] bf16
         lab = labels.to(torch.int32).contiguous()
-        lse, _, stat = _raw().ce_fwd(logits, lab, ignore)
-        ctx.save_for_backward(x, weight, logits, lab, lse, stat)
+        lse, _, stat = _raw().ce_fwd(logits, lab, ignore, row_weight)
+        ctx.save_for_backward(x, weight, logits, lab, lse, stat, row_weight)
         ctx.ignore = ignore
         return stat[0].clone()
 
     @staticmethod
     def backward(ctx, g):
-        x, weight, logits, lab, lse, stat = ctx.saved_tensors
+        x, weight, logits, lab, lse, stat, row_weight = ctx.saved_tensors
         v, k = weight.shape
         up = g.reshape(1).to(torch.float32)
-        d = _raw().ce_bwd(logits, lab, lse, up, stat, ctx.ignore)          # [M, round_up(V, 64)], zero padding
+        d = _raw().ce_bwd(logits, lab, lse, up, stat, ctx.ignore, row_weight)   # [M, round_up(V, 64)], zero padding
         vp = d.shape[1]
         dx = dw = None
         if ctx.needs_input_grad[0]:
@@ -452,7 +452,7 @@ class _LinearCrossEntropy(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             full = _raw().linear_t(d, x, True, True, None, None, 0, False, _round64(x.shape[0]))   # [Vp, K]
             dw = full[:v]
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 def linear_cross_entropy_ok(x, weight) -> bool:
@@ -460,24 +460,38 @@ def linear_cross_entropy_ok(x, weight) -> bool:
             and weight.shape[0] >= 8 and weight.shape[0] * weight.shape[1] < (1 << 30))
 
 
-def linear_cross_entropy(hidden, weight, labels, ignore_index: int = -100, host_labels=None):
+def linear_cross_entropy(hidden, weight, labels, ignore_index: int = -100, host_labels=None,
+                         per_sequence_mean: bool = False):
     """``cross_entropy(hidden @ weight^T, labels)`` (mean over the labels that are not ``ignore_index``)
     with the projection restricted to the supervised rows.  ``hidden [.., K]``, ``labels [..]``;
     ``host_labels``: a CPU copy of ``labels`` if the caller has one (the row selection is host
-    arithmetic; without it the labels are read back once)."""
+    arithmetic; without it the labels are read back once).  ``per_sequence_mean`` (``labels [B, S]``):
+    the mean over sequences of each sequence's own token mean -- what B separate single-sequence
+    steps with their losses averaged compute -- instead of the mean over all supervised tokens."""
     k = hidden.shape[-1]
     x = hidden.reshape(-1, k)
     lab = labels.reshape(-1)
-    lab_h = (host_labels if host_labels is not None else lab.detach().cpu()).reshape(-1)
-    rows = (lab_h != ignore_index).nonzero().reshape(-1)
+    lab_h2 = host_labels if host_labels is not None else labels.detach().cpu()
+    lab_h = lab_h2.reshape(-1)
+    live = lab_h != ignore_index
+    rows = live.nonzero().reshape(-1)
+    wrow = None
+    if per_sequence_mean and lab_h2.dim() == 2 and rows.numel():
+        per = (lab_h2 != ignore_index).sum(1)                        # supervised tokens of each sequence
+        n_seq = int((per > 0).sum())
+        wfull = (1.0 / (per.clamp(min=1).float() * max(n_seq, 1)))[:, None].expand_as(lab_h2).reshape(-1)
+        wrow = wfull[rows].contiguous()
     if not linear_cross_entropy_ok(x, weight) or k % 8 or rows.numel() == 0:
+        if not rows.numel():
+            return x.sum() * 0.0
         sel = rows.to(x.device)
-        return F.cross_entropy(F.linear(x[sel], weight.to(x.dtype)).float(), lab[sel], ignore_index=ignore_index) \
-            if rows.numel() else x.sum() * 0.0
+        per_row = F.cross_entropy(F.linear(x[sel], weight.to(x.dtype)).float(), lab[sel], reduction="none")
+        return per_row.mean() if wrow is None else (per_row * wrow.to(x.device)).sum()
     idx = rows.to(torch.int32).to(x.device, non_blocking=True)
     xs = _GatherRows.apply(x, idx) if rows.numel() < x.shape[0] else x.contiguous()
     ls = lab_h[rows].to(torch.int32).to(x.device, non_blocking=True)
-    return _LinearCrossEntropy.apply(xs, weight, ls, int(ignore_index))
+    wd = None if wrow is None else wrow.to(x.device, non_blocking=True)
+    return _LinearCrossEntropy.apply(xs, weight, ls, int(ignore_index), wd)
 
 
 class _LowRank(torch.autograd.Function):

@@ -93,3 +93,31 @@ def test_two_ranks(dataset_dir, tmp_path):
     assert meta["world_size"] == 2 and len(meta["history"]) == 2
     assert meta["history"][-1]["steps"] == 6                     # 3 samples per rank per epoch
     assert os.path.exists(os.path.join(out, "mm_projector.pt"))
+
+
+def test_micro_batches_take_the_same_steps_as_single_samples(tmp_path):
+    """Samples of an accumulation window run as ONE right-padded forward / backward (no attention mask:
+    causal attention never looks at the padding behind a sequence) and the mean of the per-sample losses:
+    parameters after training equal those of the one-sample-at-a-time loop."""
+    from eventgpt_amd.models import EventChatConfig, EventChatModel
+    from eventgpt_amd.parallel.dist import DistInfo
+    from eventgpt_amd.pipeline.dataset import InstructionDataset
+    # answers of different lengths, so the windows really are padded
+    ds_dir = make_synthetic_dataset(str(tmp_path / "ds"), n_samples=8, n_events=3000, width=64, height=48)
+    meta = json.load(open(os.path.join(ds_dir, "EventGPT_Instruction_Subset.json")))
+    for i, smp in enumerate(meta):
+        smp["conversations"][1]["value"] = "A synthetic scene" + " with cars" * (i % 4) + "."
+    json.dump(meta, open(os.path.join(ds_dir, "EventGPT_Instruction_Subset.json"), "w"))
+    got = {}
+    for mb in (1, 4, 3):
+        model = EventChatModel.from_config(EventChatConfig.tiny(), torch.float32, "cpu", seed=0)
+        tr = T.SFTTrainer(model, ByteTokenizer(), InstructionDataset(ds_dir), DistInfo(), "full", 2,
+                          learning_rate=2e-3, gradient_accumulation=4, micro_batch=mb,
+                          output_dir=str(tmp_path / f"mb{mb}"))
+        res = tr.train(num_epochs=2, save_every_epoch=False)
+        assert res["steps"] == 4
+        got[mb] = (torch.cat([p.detach().reshape(-1) for p in model.parameters()]),
+                   [h["train_loss"] for h in res["history"]])
+    for mb in (4, 3):
+        assert torch.allclose(got[mb][0], got[1][0], atol=2e-5), (mb, (got[mb][0] - got[1][0]).abs().max())
+        assert all(abs(a - b) < 1e-4 for a, b in zip(got[mb][1], got[1][1])), (got[mb][1], got[1][1])
