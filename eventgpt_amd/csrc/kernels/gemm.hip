@@ -1057,7 +1057,8 @@ int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M,
     p.k_per_split = ((ksteps + splitk - 1) / splitk) * 64;
     p.splitk = (K + p.k_per_split - 1) / p.k_per_split;
   }
-  switch (pick_cfg(M, N)) {
+  // more than 32 rows: the tile the split count was planned for (gemm_splitk picks with K in view)
+  switch (M > 32 ? pick_cfg(M, N, K) : pick_cfg(M, N)) {
     case CFG_128x128: launch_cfg<128, 128, 2, 2, 2>(p, st); break;
     case CFG_64x128: launch_cfg<64, 128, 2, 2, 3>(p, st); break;
     case CFG_64x64: launch_cfg<64, 64, 2, 2, 4>(p, st); break;

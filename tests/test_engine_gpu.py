@@ -374,7 +374,9 @@ def test_grouped_query_attention_engine_matches_module(dev, heads, kv_heads, hid
     t_graph = eng.generate(emb, 20, eos_token_id=-1)
     assert torch.equal(t_eager, t_graph)
     t_mod = m.generate_from_embeds(emb[None], max_new_tokens=20, use_engine=False, eos_token_id=-1)[0]
-    assert (t_mod[:20] == t_graph).long().cumprod(0).sum().item() >= 3, (t_mod, t_graph)
+    # module path vs engine: equal up to a bf16 near-tie of the engine's own logits at the first difference
+    from _lossless import assert_lossless
+    assert_lossless(eng, emb, t_mod[:20], t_graph)
     for G in (2, 7):
         eng.reset(); eng.prefill(emb, select="greedy")
         eng.verify(t_graph[1:1 + G].to(torch.int32))
@@ -403,9 +405,10 @@ def test_batched_engine_with_grouped_kv_heads(dev, B):
     eng.prefill_batch(prompts)
     for _ in range(9):
         eng.decode_step(True)
+    from _lossless import assert_lossless
     for b in range(B):
-        got = eng.tokens(b)
-        assert (got == want[b]).long().cumprod(0).sum().item() >= 5, (b, got.tolist(), want[b].tolist())
+        # batched rows run other kernels than the one-row step: equal up to a near-tie of the logits
+        assert_lossless(single, prompts[b], eng.tokens(b), want[b])
 
 
 def test_long_prompt_prefill_and_decode(dev):

@@ -59,21 +59,40 @@ def test_inference_flow_on_the_sample_cpu():
     assert isinstance(text, str)
 
 
-@needs_sample
+def _matched_stream(path: str) -> str:
+    """A stream with the sample's statistics (132 268 events, 640 x 480, 49 595 us, uint16 / uint8 fields,
+    time-sorted) written as the same kind of file -- a pickled dict in a ``.npy`` -- and read back through
+    the symbolic loader like the real one."""
+    from eventgpt_amd.data.events import save_event_npy, synthetic_events
+    ev = synthetic_events(132_268, 640, 480, 49_596, seed=1)
+    save_event_npy(path, ev)
+    return path
+
+
 @pytest.mark.gpu
-def test_sample_on_the_gpu_front_end_and_engine(dev):
-    """Device rasters == host rasters on the real stream; the CLI flow runs through the engine."""
+@pytest.mark.parametrize("source", ["matched", "reference"])
+def test_sample_on_the_gpu_front_end_and_engine(dev, source, tmp_path):
+    """Device rasters == host rasters on the stream; the CLI flow runs through the engine.  ``reference``
+    is the file that ships with the reference (absent on the GPU boxes: skipped there), ``matched`` a
+    generated stream of the same size, extent, duration and file format."""
     from eventgpt_amd.cli import inference as inf
     from eventgpt_amd.data import load_event_npy
     from eventgpt_amd.data.events import rasterize, slice_bounds_by_count
     from eventgpt_amd.ops import event_ops as eo
-    ev = load_event_npy(SAMPLE)
+    if source == "reference":
+        if not os.path.exists(SAMPLE):
+            pytest.skip("reference sample not present on this machine")
+        path = SAMPLE
+    else:
+        path = _matched_stream(str(tmp_path / "matched.npy"))
+    ev = load_event_npy(path)
+    assert len(ev["t"]) == 132_268 and ev["x"].dtype == np.uint16 and ev["p"].dtype == np.uint8
     d = eo.events_to_device(ev, dev)
     img = eo.rasterize_gpu(d, 5, (480, 640)).cpu().numpy()
     for i, (a, b) in enumerate(slice_bounds_by_count(len(ev["t"]), 5)):
         assert np.array_equal(img[i], rasterize(ev["x"][a:b], ev["y"][a:b], ev["p"][a:b], size=(480, 640)))
     hist, _ = eo.voxel_grid_gpu(d, 5, (480, 640))
     assert int(hist.sum()) == len(ev["t"])
-    text = inf.run(["--random_init", "stub125m", "--event_frame", SAMPLE, "--query", QUERY, "--temperature", "0",
+    text = inf.run(["--random_init", "stub125m", "--event_frame", path, "--query", QUERY, "--temperature", "0",
                     "--max_new_tokens", "8", "--device", "cuda"])
     assert isinstance(text, str)
