@@ -1005,6 +1005,25 @@ void prefill_rope_kv(const Tensor& qkv, const Tensor& q_out, const Tensor& k_cac
                                 cur_stream());
 }
 
+// x [S, K] @ w_qkv^T with RoPE + cache append in the GEMM's epilogue (head_dim 128, one sequence): q_out
+// [S, Hq * 128], k / v into k_cache / v_cache [1, Hkv, Lmax, 128] at pos0[0] + row.  Returns false (and
+// launches nothing) when the fused tile does not take the shape: the caller then runs GEMM + prefill_rope_kv.
+bool linear_qkv_rope(const Tensor& x, const Tensor& w_qkv, const Tensor& q_out, const Tensor& k_cache,
+                     const Tensor& v_cache, const Tensor& cos, const Tensor& sin, const Tensor& pos0, int64_t Hq,
+                     int64_t Hkv) {
+  check_bf16(x, "x"); check_bf16(w_qkv, "w_qkv"); check_bf16(q_out, "q_out"); check_bf16(k_cache, "k_cache");
+  check_bf16(v_cache, "v_cache"); check_f32(cos, "cos"); check_f32(sin, "sin"); check_i32(pos0, "pos0");
+  const int64_t K = x.size(-1), S = x.numel() / K;
+  if (K % 64 || S < 1 || k_cache.dim() != 4 || k_cache.size(0) != 1 || k_cache.size(3) != 128) return false;
+  TORCH_CHECK(w_qkv.dim() == 2 && w_qkv.size(1) == K && w_qkv.size(0) == (Hq + 2 * Hkv) * 128, "linear_qkv_rope: w_qkv");
+  TORCH_CHECK(q_out.numel() == S * Hq * 128 && k_cache.size(1) == Hkv && v_cache.sizes() == k_cache.sizes() &&
+              pos0.numel() >= 1 && cos.size(-1) == 64 && sin.size(-1) == 64 && cos.size(0) >= k_cache.size(2) &&
+              sin.size(0) >= k_cache.size(2), "linear_qkv_rope: shapes");
+  return evgpt::launch_gemm_qkv_rope(bptr(x), bptr(w_qkv), (int)S, (int)K, bptr_mut(q_out), bptr_mut(k_cache),
+                                     bptr_mut(v_cache), cos.data_ptr<float>(), sin.data_ptr<float>(),
+                                     pos0.data_ptr<int>(), (int)Hq, (int)Hkv, (int)k_cache.size(2), cur_stream());
+}
+
 // Row argmax of (x @ w^T + bias) without materialising the product: the GEMM
 // epilogue leaves per-(row, column-slab) partials; returns (val [M,P], idx [M,P]).
 std::tuple<Tensor, Tensor> linear_argmax_partials(const Tensor& x, const Tensor& w,
@@ -1324,5 +1343,6 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("attn_d512(Tensor q, Tensor k, Tensor v, bool causal, float scale) -> Tensor", &attn_d512);
   m.def("naive_sd_sync(Tensor t_pos, Tensor t_step, Tensor t_cur, Tensor t_out, int offset, Tensor embed, Tensor prompt_last, Tensor(a!) rows, Tensor(b!) d_pos0, Tensor(c!) d_pos, Tensor(d!) d_step, Tensor(e!) d_done, int l_max) -> ()", &naive_sd_sync);
   m.def("sample_top_p(Tensor logits, Tensor(a!) out, float temperature, float top_p, int seed, Tensor step, int top_k=0) -> ()", &sample_top_p);
+  m.def("linear_qkv_rope(Tensor x, Tensor w_qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos0, int Hq, int Hkv) -> bool", &linear_qkv_rope);
   m.def("prefill_rope_kv(Tensor qkv, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos0, int Hq, int Hkv, int D) -> ()", &prefill_rope_kv);
 }

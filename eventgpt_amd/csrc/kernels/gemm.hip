@@ -79,6 +79,13 @@ struct GemmParams {
   // (0: K itself).  K is then the contraction rounded up to 64, and the last K-tile's chunks past
   // k_cols -- which in memory are the start of the next row -- are staged as zeros.
   int k_cols;
+  // RoPE + cache-append epilogue of a q | k | v projection (ROPE instance of the 128 x 128 tile, head_dim
+  // 128 so that a column tile is one head): rotated q rows go to rope_q [M][Hq * 128], rotated k and
+  // plain v rows into the cache slices rope_k / rope_v [Hkv][l_max][128] at position pos0[0] + row.
+  bf16_t* rope_q; bf16_t* rope_k; bf16_t* rope_v;
+  const float* rope_cos; const float* rope_sin;     // [l_max][64]
+  const int* rope_pos0;
+  int rope_hq, rope_hkv, rope_lmax;
 };
 
 // wait until at most `n` of this wave's direct-to-LDS loads are still in flight
@@ -259,7 +266,67 @@ __device__ __forceinline__ void buffer_to_lds16(const unsigned char* src, int by
 // KT: a K-contiguous operand's rows end inside the last K-tile (GemmParams::k_cols > 0).  A template
 // parameter, not a run-time test: with the extra staging path compiled into every instance the 64-row
 // configurations ran 5-15 % slower on contractions that never needed it.
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool AT = false, bool BT = false, bool KT = false>
+// RoPE epilogue for a 128 x 128 tile of 2 x 2 waves (each 64 x 64): the rotate-half partner of column d
+// of a head is column d + 64, i.e. the same lane and register of the wave next door, so the two wave
+// columns swap their bf16-rounded tiles through LDS (free once the K loop has ended) and each lane
+// rotates and stores its own 4-column runs.  Same rounding and cache rules as rope_kv_prefill_kernel.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_rope_epilogue(const GemmParams& p, f32x4_t (&acc)[TM][TN], unsigned char* smem,
+                                                   int m0, int n0, int wid, int lane) {
+  static_assert(TM == 4 && TN == 4, "128 x 128 tile, 2 x 2 waves");
+  const int wr = wid >> 1, wc = wid & 1, frow = lane & 15, fq = lane >> 4;
+  const int head = n0 >> 7;
+  const bool is_v = head >= p.rope_hq + p.rope_hkv;
+  float* xch = reinterpret_cast<float*>(smem);        // [4 waves][64 values][64 lanes]
+  __syncthreads();                                    // every wave is done with the operand tiles
+  if (!is_v) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          xch[(wid * 64 + i * 16 + j * 4 + r) * 64 + lane] = bf16_to_f32(f32_to_bf16(acc[i][j][r]));
+  }
+  __syncthreads();
+  const int pos_base = p.rope_pos0 ? p.rope_pos0[0] : 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wr * 64 + i * 16 + frow;
+    if (m >= p.M) continue;
+    int pos = pos_base + m;
+    const bool in_cache = pos >= 0 && pos < p.rope_lmax;
+    pos = pos < 0 ? 0 : (pos >= p.rope_lmax ? p.rope_lmax - 1 : pos);
+    bf16_t* dst;
+    if (head < p.rope_hq) dst = p.rope_q + (static_cast<size_t>(m) * p.rope_hq + head) * 128;
+    else if (!in_cache) continue;
+    else if (!is_v) dst = p.rope_k + (static_cast<size_t>(head - p.rope_hq) * p.rope_lmax + pos) * 128;
+    else dst = p.rope_v + (static_cast<size_t>(head - p.rope_hq - p.rope_hkv) * p.rope_lmax + pos) * 128;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int dl = j * 16 + fq * 4;               // column inside this wave's half of the head
+      float v[4];
+      if (is_v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+      } else {
+        const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(p.rope_cos + static_cast<size_t>(pos) * 64 + dl);
+        const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(p.rope_sin + static_cast<size_t>(pos) * 64 + dl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float own = bf16_to_f32(f32_to_bf16(acc[i][j][r]));
+          const float oth = xch[((wid ^ 1) * 64 + i * 16 + j * 4 + r) * 64 + lane];
+          v[r] = wc == 0 ? own * cs[r] - oth * sn[r] : own * cs[r] + oth * sn[r];
+        }
+      }
+      const u32x2_t w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      *reinterpret_cast<u32x2_t*>(dst + wc * 64 + dl) = w;
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool AT = false, bool BT = false, bool KT = false,
+          bool ROPE = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   static_assert(!AT || BM == 64 || BM == 128, "K-strided A needs a 64- or 128-row tile");
   static_assert(!BT || BN == 64 || BN == 128, "K-strided W needs a 64- or 128-column tile");
@@ -434,7 +501,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     cur = cur + 1 == STAGES ? 0 : cur + 1;
   }
 
-  gemm_epilogue<TM, TN, WM, WN, WGN>(p, acc, m0, n0, wr, wc, tn, tiles_n, ksplit, lane);
+  if constexpr (ROPE) {
+    static_assert(BM == 128 && BN == 128 && WGM == 2 && WGN == 2 && STAGES * (BM + BN) * BK * 2 >= 65536, "rope tile");
+    gemm_rope_epilogue<TM, TN>(p, acc, smem, m0, n0, wid, lane);
+  } else {
+    gemm_epilogue<TM, TN, WM, WN, WGN>(p, acc, m0, n0, wr, wc, tn, tiles_n, ksplit, lane);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -681,18 +753,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool AT = false, bool BT = false, bool KT = false>
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool AT = false, bool BT = false, bool KT = false,
+          bool ROPE = false>
 static void launch_cfg(const GemmParams& p, hipStream_t st) {
   const int bn_out = p.glu_half ? BN / 2 : BN;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + bn_out - 1) / bn_out) * p.splitk;
   constexpr size_t smem = static_cast<size_t>(STAGES) * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES, AT, BT, KT>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES, AT, BT, KT, ROPE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES, AT, BT, KT>), dim3(tiles), dim3(256), smem,
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES, AT, BT, KT, ROPE>), dim3(tiles), dim3(256), smem,
                      st, p);
 }
 
@@ -941,6 +1014,22 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
   }
+}
+
+// q | k | v projection of a prefill with RoPE and the cache append in the epilogue (head_dim 128): A [M][K],
+// W [(Hq + 2 Hkv) * 128][K]; rotated q -> q_out [M][Hq * 128], k / v -> cache slices [Hkv][l_max][128] at
+// pos0[0] + row.  Returns false (nothing launched) for shapes the fused tile does not take.
+bool launch_gemm_qkv_rope(const bf16_t* A, const bf16_t* W, int M, int K, bf16_t* q_out, bf16_t* k_cache,
+                          bf16_t* v_cache, const float* cos_tab, const float* sin_tab, const int* pos0, int Hq,
+                          int Hkv, int l_max, hipStream_t st) {
+  const int N = (Hq + 2 * Hkv) * 128;
+  if (K % 64 || M < 1 || g_forced_cfg >= 0) return false;
+  GemmParams p{A, W, nullptr, nullptr, nullptr, nullptr, M, N, K, K, K, N, ACT_NONE, nullptr, nullptr, 1, K,
+               nullptr, 0, K, K};
+  p.rope_q = q_out; p.rope_k = k_cache; p.rope_v = v_cache; p.rope_cos = cos_tab; p.rope_sin = sin_tab;
+  p.rope_pos0 = pos0; p.rope_hq = Hq; p.rope_hkv = Hkv; p.rope_lmax = l_max;
+  launch_cfg<128, 128, 2, 2, 2, false, false, false, true>(p, st);
+  return true;
 }
 
 // dX = dY W of a few hundred tokens is a narrow output (tokens x 4096) over a contraction of

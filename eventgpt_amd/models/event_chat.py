@@ -321,7 +321,7 @@ class EventChatModel(nn.Module):
     def visval_encode(self, event_tensor: torch.Tensor) -> torch.Tensor:
         """``[B,3,H,W]`` → projector output ``[B, 577, hidden]`` (tower is frozen)."""
         if (torch.is_grad_enabled() and event_tensor.is_cuda and self.dtype == torch.bfloat16
-                and getattr(self, "train_tower_on_engine", True)):
+                and getattr(self, "train_tower_on_engine", True) and self._vision_engine_fits()):
             # a training step: the frozen tower is one graph replay of the serving engine's launch
             # sequence instead of ~300 eager launches; projector and adaptor stay on autograd
             feats = self.vision_engine().encode_tower(event_tensor)
@@ -336,7 +336,8 @@ class EventChatModel(nn.Module):
     def encode_event_frames(self, frames: Sequence[torch.Tensor]) -> torch.Tensor:
         """All frames of one sample in one tower batch → pooled ``[T+S, hidden]``."""
         batch = torch.stack([f.to(self.device) for f in frames])
-        if batch.is_cuda and self.dtype == torch.bfloat16 and not torch.is_grad_enabled():
+        if (batch.is_cuda and self.dtype == torch.bfloat16 and not torch.is_grad_enabled()
+                and self._vision_engine_fits()):
             return self.vision_engine().encode(batch)
         feats = self.visval_encode(batch)
         if hasattr(self.get_model(), "feature_adaptor"):
@@ -579,6 +580,14 @@ class EventChatModel(nn.Module):
         return seq
 
     # ------------------------------------------------------------------- engine
+    def _vision_engine_fits(self) -> bool:
+        """The captured tower takes the kernels' geometries (width a multiple of 64, heads of 64 or 128);
+        a tower outside them -- the small stand-ins of tests and CPU stubs moved to a GPU -- runs the
+        module path, whose ops pick per call."""
+        vc = self.config.vision_config
+        hd = vc.hidden_size // vc.num_attention_heads
+        return vc.hidden_size % 64 == 0 and hd in (64, 128)
+
     def vision_engine(self, **kwargs):
         """Graph-captured event tower bound to this model's weights."""
         if getattr(self, "_vision_engine", None) is None:

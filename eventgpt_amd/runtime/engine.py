@@ -388,6 +388,8 @@ class GenerationEngine:
             return self._forward_rows_gemv(embeds, batch, pos0)
         if self._few_rows_ok(S):
             return self._forward_rows_fused(embeds, batch, pos0)
+        if self._prompt_fused_ok(S):
+            return self._forward_rows_prompt(embeds, batch, pos0)
         x = embeds.to(torch.bfloat16).contiguous().view(1, S, self.H)
         kv_len = pos0 + S
         q = torch.empty(1, S, self.Hq, self.D, dtype=torch.bfloat16, device=self.device)
@@ -402,6 +404,43 @@ class GenerationEngine:
             xn = raw.rmsnorm(x, l.norm2, self.eps)
             x = raw.linear(self._mlp_up(xn, self._w(l, "w_gate_up")), self._w(l, "w_down"), None, x, 0, False)
         return x
+
+    # A prompt of up to this many rows (one event prompt is 636) is a GEMM of only 5 x 32 tiles of
+    # 128 x 128 on 256 CUs, so its row-parallel projections split K anyway; they stop at the fp32
+    # slabs and the kernel that sums them also adds the residual and applies the next RMSNorm, and
+    # the q | k | v projection rotates and appends to the cache in its own epilogue: 5 launches a
+    # layer instead of 8.
+    prompt_fused_rows = 1024
+
+    def _prompt_fused_ok(self, rows: int) -> bool:
+        return (32 < rows <= self.prompt_fused_rows and self.H % 64 == 0 and self.I % 64 == 0
+                and (self.Hq * self.D) % 64 == 0)
+
+    def _forward_rows_prompt(self, embeds: torch.Tensor, batch: int, pos0: torch.Tensor) -> torch.Tensor:
+        raw = self.raw
+        S = embeds.shape[0]
+        x = embeds.to(torch.bfloat16).contiguous().view(S, self.H)
+        kv_len = pos0 + S
+        q = torch.empty(1, S, self.Hq, self.D, dtype=torch.bfloat16, device=self.device)
+        o = torch.empty_like(q)
+        xn = raw.rmsnorm(x, self.layers[0].norm1, self.eps)
+        n = len(self.layers)
+        rope_gemm = self.D == 128
+        for i, l in enumerate(self.layers):
+            kc, vc = l.k_cache[batch:batch + 1], l.v_cache[batch:batch + 1]
+            w_qkv = self._w(l, "w_qkv")
+            if not (rope_gemm and raw.linear_qkv_rope(xn, w_qkv, q, kc, vc, self.cos, self.sin, pos0,
+                                                      self.Hq, self.Hkv)):
+                rope_gemm = False
+                qkv = raw.linear(xn, w_qkv, None, None, 0, False)
+                raw.prefill_rope_kv(qkv, q, kc, vc, self.cos, self.sin, pos0, self.Hq, self.Hkv, self.D)
+            raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
+            x, xn = self._reduce_residual_norm(self._row_partial(o.view(S, self.Hq * self.D), self._w(l, "w_o")),
+                                               x, l.norm2)
+            h = self._mlp_up(xn, self._w(l, "w_gate_up"))
+            nxt = self.layers[i + 1].norm1 if i + 1 < n else None
+            x, xn = self._reduce_residual_norm(self._row_partial(h, self._w(l, "w_down")), x, nxt)
+        return x.view(1, S, self.H)
 
     # ----------------------------------------------------- speculative verify
     @torch.no_grad()

@@ -437,3 +437,67 @@ def test_long_prompt_prefill_and_decode(dev):
     assert int(eng.pos[0]) == S + 11          # the prefill commits token 1, eleven decode steps follow
     with pytest.raises(ValueError):
         eng.prefill(torch.zeros(3073, 256, dtype=torch.bfloat16, device=dev), start=0)
+
+
+@pytest.mark.parametrize("S,Hq,Hkv,K,p0,l_max", [(636, 32, 32, 4096, 0, 1024), (77, 4, 4, 512, 5, 80),
+                                                  (300, 8, 2, 1024, 17, 512), (129, 4, 1, 512, 0, 128)])
+def test_qkv_gemm_with_rope_epilogue_equals_gemm_then_rope(dev, S, Hq, Hkv, K, p0, l_max):
+    """The q | k | v GEMM whose epilogue rotates and appends to the cache writes exactly what the plain
+    GEMM followed by the RoPE / append kernel writes (same bf16 rounding points), including rows that
+    fall past the end of the cache, grouped K/V heads and a non-zero start position."""
+    from eventgpt_amd import ops
+    raw = torch.ops.evgpt
+    g = torch.Generator(device=dev).manual_seed(S + K)
+    x = (torch.randn(S, K, device=dev, generator=g)).to(torch.bfloat16)
+    w = (torch.randn((Hq + 2 * Hkv) * 128, K, device=dev, generator=g) * K ** -0.5).to(torch.bfloat16)
+    cos, sin = ops.rope_tables(l_max, 128, 10000.0, dev)
+    cos, sin = cos.contiguous(), sin.contiguous()
+    pos0 = torch.tensor([p0], dtype=torch.int32, device=dev)
+
+    def caches():
+        return (torch.full((1, Hkv, l_max, 128), 7.0, dtype=torch.bfloat16, device=dev),
+                torch.full((1, Hkv, l_max, 128), -7.0, dtype=torch.bfloat16, device=dev))
+
+    q1 = torch.empty(1, S, Hq, 128, dtype=torch.bfloat16, device=dev)
+    k1, v1 = caches()
+    raw.prefill_rope_kv(raw.linear(x, w, None, None, 0, False), q1, k1, v1, cos, sin, pos0, Hq, Hkv, 128)
+    q2 = torch.empty_like(q1)
+    k2, v2 = caches()
+    assert raw.linear_qkv_rope(x, w, q2, k2, v2, cos, sin, pos0, Hq, Hkv)
+    assert torch.equal(q1, q2) and torch.equal(k1, k2) and torch.equal(v1, v2)
+    # and against fp32 arithmetic of the same thing
+    y = (x.float() @ w.float().T).to(torch.bfloat16).float().view(S, Hq + 2 * Hkv, 128)
+    pos = (p0 + torch.arange(S, device=dev)).clamp(max=l_max - 1)
+    c, s = cos[pos][:, None, :], sin[pos][:, None, :]
+    a, b = y[..., :64], y[..., 64:]
+    rot = torch.cat([a * c - b * s, b * c + a * s], -1)
+    err = (q2[0].float() - rot[:, :Hq]).abs().max().item()
+    assert err < 0.02 * float(rot.abs().max()) + 1e-3, err
+    n_in = min(S, l_max - p0)
+    kk = rot[:n_in, Hq:Hq + Hkv].transpose(0, 1)
+    assert (k2[0, :, p0:p0 + n_in].float() - kk).abs().max().item() < 0.02 * float(kk.abs().max()) + 1e-3
+    assert torch.all(k2[0, :, :p0] == 7.0) and torch.all(v2[0, :, p0 + n_in:] == -7.0)
+
+
+def test_prompt_path_equals_plain_path(model, dev):
+    """A prompt between 33 and 1024 rows runs with the residual add + next RMSNorm inside the split-K
+    slab sum and RoPE inside the q | k | v GEMM: same tokens and (up to fp32-vs-bf16 summation of the
+    slabs) the same hidden states as the one-kernel-per-op path."""
+    S = 200
+    emb = (torch.randn(S, 512, device=dev) * 0.5).to(torch.bfloat16)
+    eng = model.engine(max_len=512, max_new_tokens=32)
+    assert eng._prompt_fused_ok(S)
+    eng.reset()
+    h_fused = eng.prefill(emb, select=None, return_hidden=True).float()
+    k_fused = eng.layers[2].k_cache[0, :, :S].clone()
+    eng.prompt_fused_rows = 0
+    try:
+        eng.reset()
+        h_plain = eng.prefill(emb, select=None, return_hidden=True).float()
+        k_plain = eng.layers[2].k_cache[0, :, :S].clone()
+    finally:
+        del eng.prompt_fused_rows
+    cos = torch.nn.functional.cosine_similarity(h_fused, h_plain, dim=-1)
+    assert float(cos.min()) > 0.9995, float(cos.min())
+    assert (h_fused - h_plain).abs().max().item() < 0.03 * float(h_plain.abs().max())
+    assert (k_fused.float() - k_plain.float()).abs().max().item() < 0.05 * float(k_plain.abs().max())
