@@ -37,7 +37,7 @@ import torch.distributed as dist
 from torch import nn
 
 from .. import ops
-from ..runtime.engine import GenerationEngine, _Layer
+from ..runtime.engine import GenerationEngine, _Layer, persistent_state
 
 
 def _round_up(x: int, m: int) -> int:
@@ -224,6 +224,7 @@ class TensorParallelEngine(GenerationEngine):
     against RCCL passes).  Greedy selection gathers 8 bytes per row and rank.
     """
 
+    @persistent_state
     def __init__(self, model, group=None, max_len: int = 2048, max_batch: int = 1,
                  allreduce: Optional[str] = None, **kw):
         self._group_arg = group

@@ -31,7 +31,9 @@ allocations per token (pipeline/benchmark_e2e/benchmark_e2e_wallclock.py:417-472
 """
 from __future__ import annotations
 
+import contextlib
 import dataclasses
+import functools
 import math
 from typing import List, Optional
 
@@ -60,7 +62,30 @@ def _pad_rows(w: torch.Tensor, mult: int) -> torch.Tensor:
     return torch.cat([w, w.new_zeros(pad, w.shape[1])])
 
 
+@contextlib.contextmanager
+def capture_tensor_mode():
+    """Tensor mode for a graph capture: plain ``no_grad``, also inside a caller's ``torch.inference_mode()``.
+    A capture allocates tensors that outlive it (the graph's static outputs, and the seed / offset
+    tensors torch attaches to the default generator while any graph is alive); allocated under
+    inference mode they are inference tensors, and the next capture or replay bookkeeping that updates
+    them outside inference mode raises and leaves the generator stuck in its capturing state."""
+    with torch.inference_mode(False), torch.no_grad():
+        yield
+
+
+def persistent_state(method):
+    """Decorator for methods that allocate tensors an engine keeps and later updates in place (its
+    state, caches, static graph inputs): they run in ``capture_tensor_mode`` so that an engine built or
+    first used under ``torch.inference_mode()`` still works outside it."""
+    @functools.wraps(method)
+    def wrapped(*args, **kwargs):
+        with capture_tensor_mode():
+            return method(*args, **kwargs)
+    return wrapped
+
+
 class GenerationEngine:
+    @persistent_state
     def __init__(self, model, max_len: int = 2560, max_batch: int = 1, nsplit: int = 16,
                  use_graph: bool = True, max_new_tokens: int = 1024, poll_every: int = 16,
                  weight_format: str = "bf16", release_bf16: bool = False):
@@ -432,7 +457,7 @@ class GenerationEngine:
             if not (rope_gemm and raw.linear_qkv_rope(xn, w_qkv, q, kc, vc, self.cos, self.sin, pos0,
                                                       self.Hq, self.Hkv)):
                 rope_gemm = False
-                qkv = raw.linear(xn, w_qkv, None, None, 0, False)
+                qkv = raw.linear(xn, w_qkv, None, None, 0, False).view(1, S, -1)
                 raw.prefill_rope_kv(qkv, q, kc, vc, self.cos, self.sin, pos0, self.Hq, self.Hkv, self.D)
             raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
             x, xn = self._reduce_residual_norm(self._row_partial(o.view(S, self.Hq * self.D), self._w(l, "w_o")),
@@ -474,7 +499,8 @@ class GenerationEngine:
         # current token and the EOS id are all read from device memory
         entry = self._verify_graphs.get((G, self.eos))
         if entry is None:
-            static_draft = torch.zeros(G, dtype=torch.int32, device=self.device)
+            with capture_tensor_mode():
+                static_draft = torch.zeros(G, dtype=torch.int32, device=self.device)
             static_draft.copy_(draft)
             box = {}
             keep = [t.clone() for t in (self.out_tokens, self.sd_result)]
@@ -554,7 +580,7 @@ class GenerationEngine:
             g = torch.cuda.CUDAGraph()
             # thread-local capture mode: another host thread driving a second engine on
             # its own stream must not invalidate this capture
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with capture_tensor_mode(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
         finally:
             for t, s in zip(state, saved):

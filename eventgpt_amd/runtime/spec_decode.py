@@ -39,6 +39,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import torch
 
 from .. import ops
+from .engine import persistent_state
 
 
 @dataclasses.dataclass
@@ -166,6 +167,7 @@ class NaiveSpeculativeDecoder:
         self._rows = None
 
     # ------------------------------------------------------ device-resident rounds
+    @persistent_state
     def _state(self) -> None:
         d, t = self.draft, self.target
         if self._rows is None:

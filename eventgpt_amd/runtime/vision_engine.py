@@ -24,9 +24,11 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from ..ops.hip import ACT_CODES
+from .engine import capture_tensor_mode, persistent_state
 
 
 class VisionEngine:
+    @persistent_state
     def __init__(self, model, use_graph: bool = True, tower=None, projector=None,
                  adaptor="auto", feature_layer: int = -1):
         """``tower``/``projector``/``adaptor`` default to the EventChat modules of
@@ -134,16 +136,17 @@ class VisionEngine:
         key = (tuple(px.shape), pool, n_temporal, tower_only)
         entry = self._graphs.get(key)
         if entry is None:
-            static_in = px.clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                self._forward(static_in, pool, n_temporal, tower_only)     # warm-up
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                static_out = self._forward(static_in, pool, n_temporal, tower_only)
+            with capture_tensor_mode():
+                static_in = px.clone()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._forward(static_in, pool, n_temporal, tower_only)     # warm-up
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    static_out = self._forward(static_in, pool, n_temporal, tower_only)
             entry = (g, static_in, static_out)
             self._graphs[key] = entry
         g, static_in, static_out = entry

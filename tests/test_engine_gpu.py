@@ -440,7 +440,7 @@ def test_long_prompt_prefill_and_decode(dev):
 
 
 @pytest.mark.parametrize("S,Hq,Hkv,K,p0,l_max", [(636, 32, 32, 4096, 0, 1024), (77, 4, 4, 512, 5, 80),
-                                                  (300, 8, 2, 1024, 17, 512), (129, 4, 1, 512, 0, 128)])
+                                                  (300, 8, 2, 1024, 17, 512), (129, 4, 1, 512, 40, 160)])
 def test_qkv_gemm_with_rope_epilogue_equals_gemm_then_rope(dev, S, Hq, Hkv, K, p0, l_max):
     """The q | k | v GEMM whose epilogue rotates and appends to the cache writes exactly what the plain
     GEMM followed by the RoPE / append kernel writes (same bf16 rounding points), including rows that
@@ -460,7 +460,7 @@ def test_qkv_gemm_with_rope_epilogue_equals_gemm_then_rope(dev, S, Hq, Hkv, K, p
 
     q1 = torch.empty(1, S, Hq, 128, dtype=torch.bfloat16, device=dev)
     k1, v1 = caches()
-    raw.prefill_rope_kv(raw.linear(x, w, None, None, 0, False), q1, k1, v1, cos, sin, pos0, Hq, Hkv, 128)
+    raw.prefill_rope_kv(raw.linear(x, w, None, None, 0, False).view(1, S, -1), q1, k1, v1, cos, sin, pos0, Hq, Hkv, 128)
     q2 = torch.empty_like(q1)
     k2, v2 = caches()
     assert raw.linear_qkv_rope(x, w, q2, k2, v2, cos, sin, pos0, Hq, Hkv)
@@ -501,3 +501,26 @@ def test_prompt_path_equals_plain_path(model, dev):
     assert float(cos.min()) > 0.9995, float(cos.min())
     assert (h_fused - h_plain).abs().max().item() < 0.03 * float(h_plain.abs().max())
     assert (k_fused.float() - k_plain.float()).abs().max().item() < 0.05 * float(k_plain.abs().max())
+
+
+def test_engine_first_used_under_inference_mode_works_outside_it(dev):
+    """Graph captures and engine state created while the caller is in ``torch.inference_mode()`` (the
+    command-line tool generates under it) stay usable afterwards, and the default generator is left in
+    its normal state."""
+    m = EventChatModel.from_config(_small_cfg(), torch.bfloat16, dev, seed=3)
+    emb = (torch.randn(40, 512, device=dev) * 0.5).to(torch.bfloat16)
+    with torch.inference_mode():
+        eng = m.engine(max_len=256, max_new_tokens=32)
+        a = eng.generate(emb, 8, eos_token_id=-1)
+        eng.reset(); eng.eos = -1
+        eng.prefill(emb, select="greedy")
+        eng.verify(a[1:4].to(torch.int32), 3)
+    assert eng.graph_captured
+    b = eng.generate(emb, 8, eos_token_id=-1)
+    eng.reset(); eng.eos = -1
+    eng.prefill(emb, select="greedy")
+    eng.verify(a[1:4].to(torch.int32), 3)
+    assert int(eng.sd_result[0]) == 3
+    c = eng.generate(emb, 8, eos_token_id=-1)
+    _ = torch.randn(8, device=dev)
+    assert torch.equal(a.clone(), b) and torch.equal(b, c)
