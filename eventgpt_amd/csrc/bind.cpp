@@ -1024,18 +1024,6 @@ bool linear_qkv_rope(const Tensor& x, const Tensor& w_qkv, const Tensor& q_out, 
                                      pos0.data_ptr<int>(), (int)Hq, (int)Hkv, (int)k_cache.size(2), cur_stream());
 }
 
-// read [offset, offset + nbytes) of w's storage into the memory-side cache (values dropped); 16-byte granules
-void l3_prefetch(const Tensor& w, int64_t offset_bytes, int64_t nbytes, const Tensor& sink, int64_t blocks) {
-  TORCH_CHECK(w.is_cuda() && w.is_contiguous() && sink.is_cuda() && sink.numel() >= 1 && sink.element_size() == 4,
-              "l3_prefetch: contiguous device tensor and a 4-byte sink");
-  const int64_t total = w.numel() * w.element_size();
-  TORCH_CHECK(offset_bytes >= 0 && offset_bytes % 16 == 0 && nbytes >= 0 && offset_bytes + nbytes <= total,
-              "l3_prefetch: range outside the tensor");
-  TORCH_CHECK(reinterpret_cast<uintptr_t>(w.data_ptr()) % 16 == 0, "l3_prefetch: 16-byte aligned storage");
-  evgpt::launch_l3_prefetch(static_cast<const char*>(w.data_ptr()) + offset_bytes, nbytes,
-                            static_cast<unsigned int*>(sink.data_ptr()), (int)blocks, cur_stream());
-}
-
 // Row argmax of (x @ w^T + bias) without materialising the product: the GEMM
 // epilogue leaves per-(row, column-slab) partials; returns (val [M,P], idx [M,P]).
 std::tuple<Tensor, Tensor> linear_argmax_partials(const Tensor& x, const Tensor& w,
@@ -1312,7 +1300,6 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("ce_fwd(Tensor logits, Tensor labels, int ignore, Tensor? row_weight=None) -> (Tensor, Tensor, Tensor)", &ce_fwd);
   m.def("ce_bwd(Tensor logits, Tensor labels, Tensor lse, Tensor upstream, Tensor stat, int ignore, Tensor? row_weight=None) -> Tensor", &ce_bwd);
   m.def("rows_gather(Tensor src, Tensor idx) -> Tensor", &rows_gather);
-  m.def("l3_prefetch(Tensor w, int offset_bytes, int nbytes, Tensor(a!) sink, int blocks) -> ()", &l3_prefetch);
   m.def("rows_scatter(Tensor g, Tensor idx, int R) -> Tensor", &rows_scatter);
   m.def("attn512_fwd(Tensor qkv, int H, bool causal, Tensor? kpm, float scale, float drop_p, int seed, bool save_probs) -> (Tensor, Tensor)", &attn512_fwd);
   m.def("attn512_bwd(Tensor qkv, Tensor d_out, Tensor probs, int H, float scale, float drop_p, int seed) -> Tensor", &attn512_bwd);

@@ -69,7 +69,6 @@ void launch_ce_bwd(const bf16_t* logits, long long ld, const int* labels, const 
                    const float* stat, bf16_t* dlogits, long long ldd, int M, int V, int ignore, hipStream_t st,
                    const float* wrow = nullptr);
 void launch_rows_gather(const bf16_t* src, const int* idx, bf16_t* out, int n, int K, int n_src, hipStream_t st);
-void launch_l3_prefetch(const void* src, long long bytes, unsigned int* sink, int blocks, hipStream_t st);
 void launch_rows_scatter(const bf16_t* g, const int* idx, bf16_t* out, int n, int K, int R, hipStream_t st);
 
 // ---- optim.hip

@@ -530,35 +530,13 @@ class GenerationEngine:
         raw = self.raw
         if self.w4 and self.B > int(raw.gemv_w4_max_batch()):
             raise RuntimeError(f"4-bit decode steps take up to {int(raw.gemv_w4_max_batch())} sequences")
-        pf = self.l3_prefetch if (not self.w4 and self.B == 1) else None
-        if pf:
-            main = torch.cuda.current_stream()
-            if self._pf_stream is None:
-                self._pf_stream = torch.cuda.Stream()
-                self._pf_sink = torch.zeros(1, dtype=torch.int32, device=self.device)
-            side = self._pf_stream
         for l in self.layers:
             self._gemv_qkv(l, self.x, self.q, l.k_cache, l.v_cache, self.pos, False)
-            if pf:
-                # the attention launches leave the memory interface idle: pull the next projections'
-                # weights into the die-level cache meanwhile, on a second stream
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    raw.l3_prefetch(l.w_o, 0, l.w_o.numel() * 2, self._pf_sink, pf["blocks"])
-                    if pf["gate_up_bytes"] > 0:
-                        raw.l3_prefetch(l.w_gate_up, 0, min(pf["gate_up_bytes"], l.w_gate_up.numel() * 2),
-                                        self._pf_sink, pf["blocks"])
             raw.decode_attn(self.q, l.k_cache, l.v_cache, self.attn, self.part_o, self.part_ml,
                             self.pos, self.nsplit, self.scale)
-            if pf and pf["join"] == "o_proj":
-                main.wait_stream(side)
             self._gemv_residual(l, "w_o", self.attn, self.x)
             self._gemv_mlp_up(l, self.x, self.h)
             self._gemv_residual(l, "w_down", self.h, self.x)
-            if pf and pf["join"] == "layer":
-                main.wait_stream(side)
-        if pf and pf["join"] == "step":
-            main.wait_stream(side)
 
     def _logits_and_commit(self, greedy: bool, want_logits: bool = False) -> None:
         raw = self.raw
@@ -625,10 +603,6 @@ class GenerationEngine:
             return None
 
     graph_fallback: Optional[str] = None
-    # {"blocks": n, "gate_up_bytes": n, "join": "o_proj" | "layer" | "step"} or None: see _layers_step
-    l3_prefetch: Optional[dict] = None
-    _pf_stream = None
-    _pf_sink = None
 
     @property
     def graph_captured(self) -> bool:
