@@ -72,6 +72,15 @@ class LoRALinear(nn.Module):
             return None
         return self._low(x)
 
+    def drop_p(self) -> float:
+        """The input dropout probability in effect (0 in eval mode)."""
+        d = self.lora_dropout
+        return float(d.p) if isinstance(d, nn.Dropout) and d.training else 0.0
+
+    def adapter_entry(self, offset: int):
+        """``(column offset, A, B)`` of this adapter for ``ops.lora_projection``."""
+        return (offset, self.lora_A.weight, self.lora_B.weight)
+
     def _low(self, x):
         # the scale rides on the rank-r intermediate ([rows, r]), not on the [rows, out] product
         from ..ops import lowrank_delta
@@ -86,6 +95,11 @@ class LoRALinear(nn.Module):
             return self.base(x, act=act, residual=residual)
         if act:
             raise NotImplementedError("LoRA on a layer with a fused activation is not supported")
+        from .. import ops
+        fused = ops.lora_projection(x, self.base.weight, [self.adapter_entry(0)], self.scaling, self.drop_p(),
+                                    residual) if self.base.bias is None else None
+        if fused is not None:
+            return fused
         low = self._low(x)
         extra = low if residual is None else low + residual
         # the low-rank update rides on the base GEMM's residual epilogue

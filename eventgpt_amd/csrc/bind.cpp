@@ -44,6 +44,15 @@ void check_f32(const Tensor& t, const char* name) {
               " must be a contiguous float32 GPU tensor");
 }
 
+// a [rows, cols] bf16 matrix whose rows may be strided (a column block of a wider matrix)
+void check_rows(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kBFloat16 && t.dim() == 2, name, ": 2-D bf16 GPU tensor");
+  TORCH_CHECK(t.stride(1) == 1 && t.stride(0) >= t.size(1) && t.stride(0) % 8 == 0 &&
+              (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) == 0,
+              name, ": unit column stride, row stride a multiple of 8, 16-byte aligned");
+  TORCH_CHECK(t.size(0) * t.stride(0) < (1ll << 30), name, ": addressed with 32-bit byte offsets (< 2 GiB)");
+}
+
 // ------------------------------------------------------------------ norms
 Tensor rmsnorm(const Tensor& x, const Tensor& w, double eps) {
   check_bf16(x, "x"); check_bf16(w, "weight");
@@ -156,8 +165,9 @@ Tensor linear_swiglu(const Tensor& x, const Tensor& w) {
 Tensor linear_t(const Tensor& a, const Tensor& w, bool a_t, bool w_t, const c10::optional<Tensor>& bias,
                 const c10::optional<Tensor>& res, int64_t act, bool out_f32, int64_t K,
                 const c10::optional<Tensor>& out) {
-  check_bf16(a, "a"); check_bf16(w, "w");
   TORCH_CHECK(a.dim() == 2 && w.dim() == 2 && (a_t || w_t), "linear_t: 2-D operands, at least one K-strided");
+  check_rows(a, "a"); check_rows(w, "w");     // a K-strided operand may be a column block of a wider matrix
+  TORCH_CHECK((a_t || a.is_contiguous()) && (w_t || w.is_contiguous()), "linear_t: a K-contiguous operand must be contiguous");
   TORCH_CHECK(K % 64 == 0 && K >= 64, "linear_t: padded contraction length must be a multiple of 64");
   const int64_t M = a_t ? a.size(1) : a.size(0), N = w_t ? w.size(1) : w.size(0);
   int64_t ka_rows = K, kw_rows = K;
@@ -173,7 +183,6 @@ Tensor linear_t(const Tensor& a, const Tensor& w, bool a_t, bool w_t, const c10:
   const int64_t ka = a_t ? ka_rows : a.size(1), kw = w_t ? kw_rows : w.size(1);
   TORCH_CHECK(ka >= 1 && kw >= 1 && ka <= K && kw <= K && K - std::min(ka, kw) < 64,
               "linear_t: K is the contraction rounded up to 64");
-  TORCH_CHECK(a.numel() < (1ll << 30) && w.numel() < (1ll << 30), "linear_t: operands < 2 GiB each");
   // Both kinds of operand end where their data ends: K-strided ones at their last row (the staging
   // loads are range-checked against the rows that exist), K-contiguous ones at their last column
   // (the last K-tile's chunks past it are given out-of-range offsets).  Either way the kernel sees
@@ -194,25 +203,62 @@ Tensor linear_t(const Tensor& a, const Tensor& w, bool a_t, bool w_t, const c10:
   Tensor ws;
   if (sk > 1) ws = at::empty({sk * M * N}, a.options().dtype(at::kFloat));
   evgpt::launch_gemm_bf16_t(bptr(a), bptr(w), out_f32 ? nullptr : bptr_mut(y), out_f32 ? y.data_ptr<float>() : nullptr,
-                            bptr_opt(bias), bptr_opt(res), (int)M, (int)N, (int)K, (int)a.size(1), (int)w.size(1),
+                            bptr_opt(bias), bptr_opt(res), (int)M, (int)N, (int)K, (int)a.stride(0), (int)w.stride(0),
                             (int)N, (int)act, a_t, w_t, (int)ka_rows, (int)kw_rows, cur_stream(),
                             sk > 1 ? ws.data_ptr<float>() : nullptr, sk);
   return y;
 }
 
-// t [.., R] = alpha * x [.., K] · w [R, K]^T for a low-rank adapter's R <= 16 rows: one launch, no split-K pass
-Tensor lowrank_out(const Tensor& x, const Tensor& w, double alpha) {
-  check_bf16(x, "x"); check_bf16(w, "w");
+// t [.., R] = alpha * x [.., K] · w [R, K]^T for a low-rank adapter's R <= 16 rows: one launch, no split-K pass.
+// x: contiguous, or 2-D with strided rows.  drop_p > 0: x is masked while it is loaded (keep mask of
+// (seed, element index), 1 / (1 - p) folded into alpha); lowrank_mask reproduces m (.) x for the backward.
+Tensor lowrank_out(const Tensor& x, const Tensor& w, double alpha, double drop_p, int64_t seed) {
+  check_bf16(w, "w");
   TORCH_CHECK(w.dim() == 2 && x.dim() >= 1, "lowrank_out: w is [R, K]");
+  const bool strided = x.dim() == 2 && !x.is_contiguous();
+  if (strided) check_rows(x, "x"); else check_bf16(x, "x");
   const int64_t K = x.size(-1), R = w.size(0), M = K ? x.numel() / K : 0;
   TORCH_CHECK(w.size(1) == K && K % 8 == 0 && K >= 8, "lowrank_out: K mismatch or K % 8 != 0");
   TORCH_CHECK(R >= 1 && R <= 16, "lowrank_out: 1 <= R <= 16");
   TORCH_CHECK(M < (1ll << 31) / 16 && x.numel() < (1ll << 40), "lowrank_out: too many rows");
+  TORCH_CHECK(drop_p >= 0 && drop_p < 1, "lowrank_out: 0 <= drop_p < 1");
   auto sizes = x.sizes().vec();
   sizes.back() = R;
   Tensor y = at::empty(sizes, x.options());
-  if (M > 0) evgpt::launch_lowrank_out(bptr(x), bptr(w), bptr_mut(y), (int)M, (int)R, (int)K, (float)alpha, cur_stream());
+  if (M > 0)
+    evgpt::launch_lowrank_out(bptr(x), bptr(w), bptr_mut(y), (int)M, (int)R, (int)K, strided ? x.stride(0) : K,
+                              (float)alpha, (float)drop_p, (unsigned long long)seed, cur_stream());
   return y;
+}
+
+// m (.) x with lowrank_out's keep mask (no rescaling); contiguous, a multiple of 8 elements
+Tensor lowrank_mask(const Tensor& x, double drop_p, int64_t seed) {
+  check_bf16(x, "x");
+  TORCH_CHECK(x.numel() % 8 == 0 && drop_p >= 0 && drop_p < 1, "lowrank_mask: a multiple of 8 elements");
+  Tensor y = at::empty_like(x);
+  evgpt::launch_lowrank_mask(bptr(x), bptr_mut(y), x.numel(), (float)drop_p, (unsigned long long)seed, false, cur_stream());
+  return y;
+}
+// acc += m (.) x in place
+void lowrank_mask_add_(const Tensor& acc, const Tensor& x, double drop_p, int64_t seed) {
+  check_bf16(x, "x"); check_bf16(acc, "acc");
+  TORCH_CHECK(x.numel() % 8 == 0 && acc.numel() == x.numel() && drop_p >= 0 && drop_p < 1, "lowrank_mask_add_: shapes");
+  evgpt::launch_lowrank_mask(bptr(x), bptr_mut(acc), x.numel(), (float)drop_p, (unsigned long long)seed, true, cur_stream());
+}
+
+// out [M, N] (rows may be strided: a column block of a wider matrix) = x [M, K] · w [N, K]^T (+ out when
+// accumulate); x's rows may be strided too.  The low-rank update written straight onto its columns of a
+// grouped projection.
+void linear_rows_(const Tensor& x, const Tensor& w, const Tensor& out, bool accumulate) {
+  check_rows(x, "x"); check_rows(out, "out"); check_bf16(w, "weight");
+  const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
+  TORCH_CHECK(w.dim() == 2 && w.size(1) == K && K % 8 == 0 && out.size(0) == M && out.size(1) == N && N % 4 == 0 &&
+              out.stride(0) % 4 == 0, "linear_rows_: x [M, K], w [N, K], out [M, N], K % 8 == 0");
+  TORCH_CHECK(N * K < (1ll << 30), "linear_rows_: weight < 2 GiB");
+  if (M == 0) return;
+  evgpt::launch_gemm_bf16(bptr(x), bptr(w), bptr_mut(out), nullptr, nullptr, accumulate ? bptr(out) : nullptr, (int)M,
+                          (int)N, (int)K, (int)x.stride(0), (int)K, (int)out.stride(0), 0, nullptr, nullptr, nullptr, 1,
+                          cur_stream());
 }
 
 // ---- few-row projections: GEMM to fp32 split-K slabs + a fused consumer ----
@@ -1273,7 +1319,10 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("linear(Tensor x, Tensor w, Tensor? bias, Tensor? res, int act, bool out_f32) -> Tensor", &linear);
   m.def("linear_swiglu(Tensor x, Tensor w_gate_up) -> Tensor", &linear_swiglu);
   m.def("linear_partial(Tensor x, Tensor w, int max_split=0) -> Tensor", &linear_partial);
-  m.def("lowrank_out(Tensor x, Tensor w, float alpha) -> Tensor", &lowrank_out);
+  m.def("lowrank_out(Tensor x, Tensor w, float alpha, float drop_p=0.0, int seed=0) -> Tensor", &lowrank_out);
+  m.def("lowrank_mask(Tensor x, float drop_p, int seed) -> Tensor", &lowrank_mask);
+  m.def("lowrank_mask_add_(Tensor(a!) acc, Tensor x, float drop_p, int seed) -> ()", &lowrank_mask_add_);
+  m.def("linear_rows_(Tensor x, Tensor w, Tensor(a!) out, bool accumulate) -> ()", &linear_rows_);
   m.def("linear_t(Tensor a, Tensor w, bool a_t, bool w_t, Tensor? bias, Tensor? res, int act, bool out_f32, int K, Tensor(a!)? out=None) -> Tensor", &linear_t);
   m.def("gemv_max_batch() -> int", []() -> int64_t { return evgpt::gemv_max_batch(); });
   m.def("reduce_residual_norm(Tensor partial, Tensor? res, Tensor? norm_w, float eps, Tensor(a!)? out) -> (Tensor, Tensor)", &reduce_residual_norm);

@@ -163,8 +163,10 @@ void launch_rope_kv_prefill(const bf16_t* qkv, bf16_t* q_out, bf16_t* k_cache, b
                             const float* cos_tab, const float* sin_tab, const int* pos0, int B,
                             int S, int Hq, int Hkv, int D, int l_max, hipStream_t st);
 // C [M, R] = alpha * A [M, K] · W [R, K]^T for R <= 16 and K % 8 == 0 (rank-r projection of a low-rank adapter)
-void launch_lowrank_out(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int R, int K, float alpha,
-                        hipStream_t st);
+void launch_lowrank_out(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int R, int K, long long lda, float alpha,
+                        float drop_p, unsigned long long seed, hipStream_t st);
+void launch_lowrank_mask(const bf16_t* x, bf16_t* y, long long n, float drop_p, unsigned long long seed, bool add,
+                         hipStream_t st);
 void launch_rope_qkv(const bf16_t* packed_in, bf16_t* packed_out, bf16_t* q, bf16_t* k, bf16_t* v,
                      const long long* positions, const float* cos_tab, const float* sin_tab, long long tokens,
                      int Hq, int Hkv, int D, int max_pos, bool merge, hipStream_t st);

@@ -118,17 +118,32 @@ class LlamaAttention(nn.Module):
         self._w_qkv = group_frozen_weights(self._qkv_bases())
         return self._w_qkv is not None
 
+    def _qkv_with_adapters(self, x, w, bases):
+        """``x W_qkv^T`` plus the low-rank updates of wrapped q / k / v on their column ranges."""
+        mods = (self.q_proj, self.k_proj, self.v_proj)
+        widths = [m.weight.shape[0] for m in bases]
+        live = [(sum(widths[:i]), m) for i, m in enumerate(mods)
+                if hasattr(m, "lora_delta") and not m.merged]
+        if not live:
+            return ops.linear(x, w)
+        if len({(m.scaling, m.drop_p()) for _, m in live}) == 1:
+            # one autograd node on the in-tree kernels: masks applied while x is loaded, updates accumulated
+            # in place onto their columns, the backward reading the gradient's column blocks where they are
+            m0 = live[0][1]
+            y = ops.lora_projection(x, w, [m.adapter_entry(off) for off, m in live], m0.scaling, m0.drop_p())
+            if y is not None:
+                return y
+        qkv = ops.linear(x, w)
+        deltas = [m.lora_delta(x) if hasattr(m, "lora_delta") else None for m in mods]
+        return ops.add_column_blocks(qkv, deltas, widths)
+
     def forward(self, x, positions, rope, past_kv, key_padding_mask, residual):
         b, s, _ = x.shape
         cos, sin = rope
         w = self.__dict__.get("_w_qkv")
         bases = self._qkv_bases() if w is not None else ()
         if w is not None and group_intact(w, bases, x):
-            qkv = ops.linear(x, w)
-            deltas = [m.lora_delta(x) if hasattr(m, "lora_delta") else None
-                      for m in (self.q_proj, self.k_proj, self.v_proj)]
-            if any(dl is not None for dl in deltas):      # low-rank updates onto their column ranges
-                qkv = ops.add_column_blocks(qkv, deltas, [m.weight.shape[0] for m in bases])
+            qkv = self._qkv_with_adapters(x, w, bases)
             q, k, v = ops.rope_qkv_split(qkv, positions, cos, sin,
                                          self.num_heads, self.num_kv_heads, self.head_dim)
         else:

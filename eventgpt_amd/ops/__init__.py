@@ -103,6 +103,18 @@ def lowrank_delta(x, a, b, scale: float):
     return linear(linear(x, a) * scale, b)
 
 
+def lora_projection(x, weight, adapters, scale: float, drop_p: float = 0.0, residual=None):
+    """``x W^T (+ residual)`` of a frozen projection with low-rank adapters ``[(column offset, A, B), ...]`` on
+    column ranges of its output and input dropout ``drop_p`` per adapter, as ONE autograd node on the
+    in-tree kernels (``ops.differentiable._LoRAProjection``) -- or None when that node does not take these
+    operands (CPU tensors, other dtypes, a trainable base, nothing to record): the caller then composes the
+    same thing from ``linear`` / ``lowrank_delta`` / ``add_column_blocks``."""
+    flat = [t for _, a, b in adapters for t in (a, b)]
+    if adapters and _train(x, weight, residual, *flat) and _diff().lora_projection_ok(x, weight, adapters, residual):
+        return _diff().lora_projection(x, weight, adapters, scale, drop_p, residual)
+    return None
+
+
 def add_column_blocks(y, blocks, widths):
     """``y[..., off_i : off_i + widths[i]] += blocks[i]`` for the blocks that are not None; ``y`` is a
     freshly computed tensor (updated in place).  Returns ``y``."""

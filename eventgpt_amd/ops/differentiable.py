@@ -347,14 +347,15 @@ class _Linear(torch.autograd.Function):
     """``y = x @ W^T + b`` on the in-tree MFMA GEMM, forward and both backward products."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, residual=None):
         k = x.shape[-1]
         xc = x if x.is_contiguous() else x.contiguous()
         ctx.save_for_backward(xc.view(-1, k), weight)
         ctx.has_bias = bias is not None
         from . import hip
-        # the kernel's own output in the input's leading shape: not a view, so a caller may update it in place
-        return hip.linear(xc, weight, bias)
+        # the kernel's own output in the input's leading shape: not a view, so a caller may update it in place;
+        # a residual is added by the GEMM's epilogue (its gradient is the incoming gradient itself)
+        return hip.linear(xc, weight, bias, None, residual)
 
     @staticmethod
     def backward(ctx, gy):
@@ -381,7 +382,7 @@ class _Linear(torch.autograd.Function):
             dw = _wgrad_to_sink(weight, g2, x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = g2.float().sum(0).to(gy.dtype)
-        return dx, dw, db
+        return dx, dw, db, (gy if ctx.needs_input_grad[3] else None)
 
 
 def _linear_fused_ok(x, weight, bias) -> bool:
@@ -394,6 +395,9 @@ def _linear_fused_ok(x, weight, bias) -> bool:
 
 def linear(x, weight, bias=None, act: Optional[str] = None, residual=None):
     if _linear_fused_ok(x, weight, bias):
+        if residual is not None and not act and _fused(residual) and residual.shape[:-1] == x.shape[:-1] \
+                and residual.shape[-1] == weight.shape[0]:
+            return _Linear.apply(x, weight, bias, residual)
         y = _Linear.apply(x, weight, bias)
     else:
         y = F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
@@ -523,6 +527,123 @@ class _LowRank(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = linear_dgrad(dt, a.detach().contiguous()).view(*gy.shape[:-1], a.shape[1])
         return dx, da, db, None
+
+
+class _LoRAProjection(torch.autograd.Function):
+    """``y = x W^T (+ residual)`` of a FROZEN projection with low-rank adapters on column ranges of its output
+    (one adapter on all columns of an ``o_proj``; three on the q / k / v ranges of a grouped projection):
+    ``y[:, off_i : off_i + n_i] += (s / (1 - p)) (m_i (.) x) A_i^T B_i^T``, ``m_i`` the adapter's input-dropout
+    keep mask.  One node instead of a dropout, a rank-r node, a strided add and their backward copies per
+    adapter:
+
+    * forward: base GEMM (residual in its epilogue), then per adapter the rank-r kernel with the mask applied
+      while ``x`` is loaded and a GEMM that accumulates ``t_i B_i^T`` in place onto its column block;
+    * backward: the base input gradient, then per adapter ``dt_i`` and ``dB_i`` read the incoming gradient's
+      column block where it is (row-strided operands), ``dA_i`` contracts with ``m_i (.) x`` recomputed from
+      the seed, and ``m_i (.) (dt_i A_i)`` is accumulated onto the input gradient in place.
+
+    Saved per node: ``x`` once and the ``[rows, r]`` intermediates -- not one dropped copy of ``x`` per adapter."""
+
+    @staticmethod
+    def forward(ctx, x, weight, residual, scale, drop_p, offsets, *ab):
+        from . import hip
+        raw = _raw()
+        k = x.shape[-1]
+        xc = x if x.is_contiguous() else x.contiguous()
+        x2 = xc.view(-1, k)
+        y = hip.linear(xc, weight, None, None, residual)
+        y2 = y.view(-1, y.shape[-1])
+        ts, seeds = [], []
+        for i, off in enumerate(offsets):
+            a, b = ab[2 * i], ab[2 * i + 1]
+            seed = next_seed() if drop_p > 0 else 0
+            t = raw.lowrank_out(x2, a, scale, drop_p, seed)                  # [M, r], scale / (1 - p) applied
+            raw.linear_rows_(t, b, y2[:, off:off + b.shape[0]], True)
+            ts.append(t)
+            seeds.append(seed)
+        ctx.save_for_backward(x2, weight, *ts, *ab)
+        ctx.meta = (float(scale), float(drop_p), tuple(offsets), tuple(seeds))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        raw = _raw()
+        scale, p, offsets, seeds = ctx.meta
+        n_ad = len(offsets)
+        x2, weight = ctx.saved_tensors[:2]
+        ts = ctx.saved_tensors[2:2 + n_ad]
+        ab = ctx.saved_tensors[2 + n_ad:]
+        ntot = weight.shape[0]
+        g2 = gy.reshape(-1, ntot)
+        g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        dx2 = None
+        if ctx.needs_input_grad[0]:
+            wt = _transposed_for_dgrad(weight)
+            if wt is not None:
+                from . import hip
+                dx2 = hip.linear(g2, wt)
+            else:
+                dx2 = linear_dgrad(g2, weight.contiguous())
+        grads = []
+        s_eff = scale / (1.0 - p)
+        kpad = _round64(g2.shape[0])
+        for i, off in enumerate(offsets):
+            a, b, t = ab[2 * i], ab[2 * i + 1], ts[i]
+            gi = g2[:, off:off + b.shape[0]]                                  # a view: rows strided by ntot
+            need_a, need_b = ctx.needs_input_grad[6 + 2 * i], ctx.needs_input_grad[7 + 2 * i]
+            da = db = None
+            dt = None
+            if need_a or dx2 is not None:
+                dt = raw.lowrank_out(gi, b.detach().t().contiguous(), s_eff, 0.0, 0)      # s / (1 - p) * dY_i B_i
+            if need_b:
+                sink = _free_sink(b, gi)
+                db = raw.linear_t(gi, t, True, True, None, None, 0, False, kpad, sink)
+                db = db.view_as(b)
+            if need_a:
+                xm = raw.lowrank_mask(x2, p, seeds[i]) if p > 0 else x2
+                da = _wgrad_to_sink(a, dt, xm)
+            if dx2 is not None:
+                if p > 0:
+                    raw.lowrank_mask_add_(dx2, linear_dgrad(dt, a.detach().contiguous()), p, seeds[i])
+                else:
+                    raw.linear_t(dt, a.detach().contiguous(), False, True, None, dx2, 0, False, _round64(a.shape[0]), dx2)
+            grads += [da, db]
+        dx = None if dx2 is None else dx2.view(*gy.shape[:-1], x2.shape[1])
+        return (dx, None, (gy if ctx.needs_input_grad[2] else None), None, None, None, *grads)
+
+
+def _free_sink(weight, g2):
+    """The parameter's published gradient slot if it is still free this step (marks it used), else None."""
+    sink = getattr(weight, "_grad_sink", None)
+    if (sink is not None and weight.grad is None and not getattr(weight, "_grad_sink_used", True)
+            and sink.dtype == g2.dtype and sink.shape == weight.shape and sink.is_contiguous()):
+        weight._grad_sink_used = True
+        return sink
+    return None
+
+
+def lora_projection_ok(x, weight, adapters, residual=None) -> bool:
+    """Shapes and dtypes ``lora_projection`` takes: bf16 GPU tensors, a frozen base, rank <= 16 (a multiple of 8)."""
+    if not _fused(x, weight) or weight.requires_grad or weight.dim() != 2 or x.numel() == 0:
+        return False
+    n, k = weight.shape
+    if n % 8 or k % 8 or x.shape[-1] != k or (residual is not None and not _fused(residual)):
+        return False
+    for off, a, b in adapters:
+        if not _fused(a, b) or a.dim() != 2 or b.dim() != 2 or not a.is_contiguous() or not b.is_contiguous():
+            return False
+        r = a.shape[0]
+        if r > 16 or r % 8 or a.shape[1] != k or b.shape[1] != r or b.shape[0] % 8 or off % 8 or off + b.shape[0] > n:
+            return False
+    return True
+
+
+def lora_projection(x, weight, adapters, scale: float, drop_p: float = 0.0, residual=None):
+    """``x W^T (+ residual)`` with low-rank updates ``adapters = [(column offset, A [r, K], B [n, r]), ...]`` on
+    column ranges of the output, input dropout ``drop_p`` per adapter (pass 0 outside training)."""
+    flat = [t for _, a, b in adapters for t in (a, b)]
+    return _LoRAProjection.apply(x, weight, residual, float(scale), float(drop_p),
+                                 tuple(int(off) for off, _, _ in adapters), *flat)
 
 
 def lowrank_delta(x, a, b, scale: float):

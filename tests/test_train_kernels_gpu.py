@@ -403,3 +403,121 @@ def test_decoder_layer_training_step_uses_only_intree_kernels(dev):
     bad = [n for n in names if n.startswith("Cijk_") or "attn_fwd" in n or "bwd_kernel_dk_dv" in n]
     assert not bad, bad
     assert emb.grad is not None and torch.isfinite(emb.grad.float()).all()
+
+
+def test_row_strided_operands_of_the_lora_products(dev):
+    """The products that read or write a column block of a wider matrix where it is: the rank-r kernel and
+    the K-strided GEMM on a row-strided gradient block, and the GEMM that accumulates onto a block in place."""
+    from eventgpt_amd.ops import hip
+    raw = hip.raw
+    M, N, r = 300, 1024, 16
+    wide = _rand(M, N, dev=dev)
+    blk = wide[:, 256:768]                                     # rows strided by 1024
+    b_t = _rand(r, 512, dev=dev, seed=1, scale=0.1)
+    assert torch.equal(raw.lowrank_out(blk, b_t, 1.5), raw.lowrank_out(blk.contiguous(), b_t, 1.5))
+    t = _rand(M, r, dev=dev, seed=2)
+    got = raw.linear_t(blk, t, True, True, None, None, 0, False, 320)
+    want = raw.linear_t(blk.contiguous(), t, True, True, None, None, 0, False, 320)
+    assert torch.equal(got, want)
+    _close(got, blk.float().t() @ t.float(), 0.3, 2e-2)
+    bw = _rand(512, r, dev=dev, seed=3, scale=0.1)
+    y = wide.clone()
+    raw.linear_rows_(t, bw, y[:, 256:768], True)
+    ref_y = wide.float().clone()
+    ref_y[:, 256:768] += (t.float() @ bw.float().t()).bfloat16().float()
+    _close(y, ref_y, 2e-2, 1e-2)
+    assert torch.equal(y[:, :256], wide[:, :256]) and torch.equal(y[:, 768:], wide[:, 768:])
+    z = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    raw.linear_rows_(t, bw, z[:, 512:], False)
+    _close(z[:, 512:], t.float() @ bw.float().t(), 2e-2, 1e-2)
+    assert float(z[:, :512].abs().max()) == 0.0
+
+
+def test_lora_input_mask_statistics_and_fused_load(dev):
+    """The keep mask of (seed, element index): the right fraction, different per seed, and the rank-r kernel
+    that applies it while loading equals the kernel run on the masked copy."""
+    from eventgpt_amd.ops import hip
+    raw = hip.raw
+    M, K, p = 333, 4096, 0.1
+    ones = torch.ones(M, K, dtype=torch.bfloat16, device=dev)
+    m1, m2 = raw.lowrank_mask(ones, p, 11), raw.lowrank_mask(ones, p, 12)
+    assert set(m1.unique().tolist()) == {0.0, 1.0}
+    assert abs(float(m1.float().mean()) - (1 - p)) < 0.005 and not torch.equal(m1, m2)
+    assert abs(float(m1.float().mean(0).min()) - (1 - p)) < 0.12      # no dead columns or rows
+    x = _rand(M, K, dev=dev) + 0.25
+    a = _rand(16, K, dev=dev, seed=1, scale=0.05)
+    fused = raw.lowrank_out(x, a, 2.0, p, 11)
+    plain = raw.lowrank_out(raw.lowrank_mask(x, p, 11), a, 2.0 / (1 - p))
+    assert torch.equal(fused, plain)
+    acc = _rand(M, K, dev=dev, seed=4)
+    want = (acc.float() + (x.float() * m1.float())).bfloat16()
+    raw.lowrank_mask_add_(acc, x, p, 11)
+    assert torch.equal(acc, want)
+
+
+@pytest.mark.parametrize("p,single", [(0.0, False), (0.1, False), (0.1, True), (0.0, True)])
+def test_lora_projection_node_against_fp32(dev, p, single):
+    """Frozen projection + low-rank adapters on column ranges as one autograd node: output, input gradient,
+    residual gradient and every adapter gradient against fp32 arithmetic with the same masks and the same
+    bf16 rank-r intermediates."""
+    from eventgpt_amd import ops
+    from eventgpt_amd.ops import differentiable as diff, hip
+    raw = hip.raw
+    K, r, s = 512, 16, 2.0
+    widths = [512] if single else [512, 256, 256]
+    N, M = sum(widths), 140
+    x = (_rand(2, 70, K, dev=dev) * 0.5).requires_grad_(True)
+    w = _rand(N, K, dev=dev, seed=1, scale=K ** -0.5)
+    res = _rand(2, 70, N, dev=dev, seed=8).requires_grad_(True) if single else None
+    ads, off = [], 0
+    for i, n in enumerate(widths):
+        a = _rand(r, K, dev=dev, seed=10 + i, scale=0.05).requires_grad_(True)
+        b = _rand(n, r, dev=dev, seed=20 + i, scale=0.05).requires_grad_(True)
+        ads.append((off, a, b))
+        off += n
+    go = _rand(2, 70, N, dev=dev, seed=3)
+    torch.manual_seed(77)
+    y = ops.lora_projection(x, w, ads, s, p, res)
+    assert y is not None and type(y.grad_fn).__name__ == "_LoRAProjectionBackward"
+    y.backward(go)
+    torch.manual_seed(77)
+    seeds = [diff.next_seed() if p > 0 else 0 for _ in ads]
+    xf, gf = x.detach().float().view(M, K), go.float().view(M, N)
+    ones = torch.ones(M, K, dtype=torch.bfloat16, device=dev)
+    se = s / (1 - p)
+    yf = (xf @ w.float().t()).bfloat16().float()
+    if res is not None:
+        yf = yf + res.detach().float().view(M, N)
+    dx = gf @ w.float()
+    for (o, a, b), seed in zip(ads, seeds):
+        n = b.shape[0]
+        mask = raw.lowrank_mask(ones, p, seed).float() if p > 0 else ones.float()
+        xm = xf * mask
+        t = (se * (xm @ a.detach().float().t())).bfloat16().float()
+        yf[:, o:o + n] = (yf[:, o:o + n].bfloat16().float() + (t @ b.detach().float().t()).bfloat16().float())
+        gi = gf[:, o:o + n]
+        dt = (se * (gi @ b.detach().float())).bfloat16().float()
+        _close(a.grad, dt.t() @ xm, 2e-2 * math.sqrt(M / 16), 2e-2)
+        _close(b.grad, gi.t() @ t, 2e-2 * math.sqrt(M / 16), 2e-2)
+        dx = dx + mask * (dt @ a.detach().float())
+    _close(y.view(M, N), yf, 3e-2, 2e-2)
+    _close(x.grad.view(M, K), dx, 4e-2, 2e-2)
+    if res is not None:
+        assert torch.equal(res.grad, go)
+
+
+def test_linear_with_residual_is_one_node(dev):
+    """``ops.linear(..., residual=r)`` under autograd adds the residual in the GEMM's epilogue; the residual's
+    gradient is the incoming gradient."""
+    from eventgpt_amd import ops
+    x = _rand(3, 50, 512, dev=dev).requires_grad_(True)
+    w = _rand(1024, 512, dev=dev, seed=1, scale=0.05).requires_grad_(True)
+    r = _rand(3, 50, 1024, dev=dev, seed=2).requires_grad_(True)
+    go = _rand(3, 50, 1024, dev=dev, seed=3)
+    y = ops.linear(x, w, None, None, r)
+    assert type(y.grad_fn).__name__ == "_LinearBackward"
+    y.backward(go)
+    _close(y, (x.detach().float() @ w.detach().float().t()).bfloat16().float() + r.detach().float(), 2e-2, 1e-2)
+    assert torch.equal(r.grad, go)
+    _close(x.grad, go.float() @ w.detach().float(), 3e-2, 2e-2)
+    _close(w.grad, go.float().view(-1, 1024).t() @ x.detach().float().view(-1, 512), 0.1, 2e-2)
