@@ -398,7 +398,7 @@ def linear(x, weight, bias=None, act: Optional[str] = None, residual=None):
         if residual is not None and not act and _fused(residual) and residual.shape[:-1] == x.shape[:-1] \
                 and residual.shape[-1] == weight.shape[0]:
             return _Linear.apply(x, weight, bias, residual)
-        y = _Linear.apply(x, weight, bias)
+        y = _Linear.apply(x, weight, bias, None)
     else:
         y = F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
     y = _ACTS[act](y)
