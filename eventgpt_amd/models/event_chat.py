@@ -394,6 +394,24 @@ class EventChatModel(nn.Module):
         # a plain tensor batch: projector output only, no adaptor / pooling
         return self.visval_encode(event_tensors)
 
+    @staticmethod
+    def _feature_positions(src, feat_cat, embed):
+        """Flat output position of every event-feature row (int32, host) when the splice can run as the
+        one-launch autograd node -- bf16 on a GPU, a frozen token table, features with a gradient, every
+        feature row used exactly once -- else None."""
+        if not (feat_cat.is_cuda and feat_cat.dtype == torch.bfloat16 and feat_cat.requires_grad
+                and not embed.weight.requires_grad and feat_cat.shape[1] % 8 == 0):
+            return None
+        flat = src.reshape(-1)
+        pos = torch.nonzero((flat < 0) & (flat > _PAD)).squeeze(1)
+        ids = -1 - flat[pos]
+        n = feat_cat.shape[0]
+        if pos.numel() != n or ids.numel() == 0 or int(ids.max()) >= n or torch.unique(ids).numel() != n:
+            return None
+        inv = torch.empty(n, dtype=torch.int32)
+        inv[ids] = pos.to(torch.int32)
+        return inv
+
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask,
                                              past_key_values, labels, event_tensors=None,
                                              event_image_sizes=None, event_features=None,
@@ -430,6 +448,11 @@ class EventChatModel(nn.Module):
             from ..ops import hip
             embeds = hip.raw.splice_rows(embed.weight.detach(), feat_cat.detach().contiguous(),
                                          src_d.to(torch.int32).contiguous())
+        elif (inv_h := self._feature_positions(src, feat_cat, embed)) is not None:
+            # frozen table, features that train, every feature row placed once: one launch each way
+            from ..ops import differentiable as diff
+            embeds = diff.splice_rows(embed.weight.detach(), feat_cat, src_d.to(torch.int32).contiguous(),
+                                      inv_h.to(dev))
         else:
             tok = embed(src_d.clamp(min=0))
             ev = feat_cat[(-1 - src_d).clamp(min=0, max=feat_cat.shape[0] - 1)]

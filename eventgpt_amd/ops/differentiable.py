@@ -421,6 +421,31 @@ class _GatherRows(torch.autograd.Function):
         return _raw().rows_scatter(g.contiguous(), idx, ctx.rows), None
 
 
+class _SpliceRows(torch.autograd.Function):
+    """Input embeddings of a multimodal prompt from a FROZEN token table and event features that train:
+    row (b, l) is ``table[src]`` for ``src >= 0``, ``feats[-1 - src]`` for an event slot, zeros for padding
+    (one launch, ``splice_rows``).  Every feature row is placed exactly once, so the features' gradient is a
+    row gather through the inverse map ``inv[j]`` = flat output position of feature row ``j`` -- not the
+    sort-and-accumulate an indexed read's backward runs."""
+
+    @staticmethod
+    def forward(ctx, table, feats, src, inv):
+        ctx.save_for_backward(inv)
+        return _raw().splice_rows(table, feats.contiguous(), src)
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv,) = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        return None, _raw().rows_gather(g2, inv), None, None
+
+
+def splice_rows(table, feats, src, inv):
+    """See ``_SpliceRows``; ``src`` int32 ``[B, L]``, ``inv`` int32 ``[feats.shape[0]]`` (both on the device)."""
+    return _SpliceRows.apply(table, feats, src, inv)
+
+
 class _LinearCrossEntropy(torch.autograd.Function):
     """Mean token cross-entropy of ``x W^T`` against ``labels`` (``csrc/kernels/loss.hip``): bf16 logits
     from the in-tree GEMM, log-sum-exp and loss per row in one pass, and in the backward the logits'
