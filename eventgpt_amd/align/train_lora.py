@@ -54,8 +54,10 @@ class LoRATrainer:
                  token_loss_weight: float = 0.1, learning_rate: float = 1e-4, gradient_accumulation: int = 16,
                  num_epochs: int = 20, early_stopping: int = 5, output_dir: str = "tasks/L6",
                  info: Optional[DistInfo] = None, double_adaptor: bool = True, max_samples: int = -1,
-                 gradient_checkpointing: str = "auto"):
+                 gradient_checkpointing: str = "auto", micro_batch: int = 1):
         self.model, self.tok = model, tokenizer
+        # samples of one accumulation window that share a forward / backward (right-padded batch)
+        self.micro_batch = max(1, min(int(micro_batch), int(gradient_accumulation)))
         self.train_chunks, self.val_chunks = train_chunks, val_chunks
         self.ds = InstructionDataset(dataset_dir)
         self.val_ds = InstructionDataset(val_dataset_dir) if val_dataset_dir else self.ds
@@ -129,15 +131,7 @@ class LoRATrainer:
     def teacher_forced_forward(self, inp: Dict) -> torch.Tensor:
         """Final-norm hidden states at the answer positions ``[gen_len, H]``."""
         m = self.model
-        with torch.no_grad():
-            px = inp["pixel_values"].to(self.device, m.dtype)
-            if px.is_cuda and m.dtype == torch.bfloat16:
-                # tower, projector, adaptor and pooling are all frozen here: one replay of the serving
-                # engine's captured launch sequence instead of ~300 eager launches
-                feats = m.encode_event_frames([px])[None].detach()
-            else:
-                feats = m.get_model().feature_adaptor(m.visval_encode(px[None]))[0]
-                feats = get_spatio_temporal_features([feats])[None].detach()
+        feats = self._event_features(inp)[None]
         ids = torch.cat([inp["input_ids"], inp["gen_token_ids"][None]], 1).to(self.device)
         embeds = m.prepare_inputs_labels_for_multimodal(
             ids, None, None, None, None, event_features=feats, event_image_sizes=[inp["event_image_size"]],
@@ -146,6 +140,44 @@ class LoRATrainer:
         out = m.model(inputs_embeds=embeds, use_cache=False)
         n = inp["gen_token_ids"].shape[0]
         return out.last_hidden_state[0, -n:]
+
+    def _event_features(self, inp: Dict) -> torch.Tensor:
+        """Pooled event tokens ``[n, H]`` of one sample; tower, projector, adaptor and pooling are frozen."""
+        m = self.model
+        with torch.no_grad():
+            px = inp["pixel_values"].to(self.device, m.dtype)
+            if px.is_cuda and m.dtype == torch.bfloat16:
+                # one replay of the serving engine's captured launch sequence instead of ~300 eager launches
+                return m.encode_event_frames([px]).detach()
+            feats = m.get_model().feature_adaptor(m.visval_encode(px[None]))[0]
+            return get_spatio_temporal_features([feats]).detach()
+
+    def teacher_forced_forward_batch(self, inps: List[Dict]) -> List[torch.Tensor]:
+        """``teacher_forced_forward`` of several samples in ONE pass over the decoder: the sequences are
+        right-padded to the longest (causal attention: a sequence's rows never see its own padding, so no
+        mask is needed) and each sample's answer rows are sliced out of the batch's hidden states.  The
+        projections then run over all samples' rows together -- the regime the GEMMs are fast in -- and
+        the values equal the one-by-one passes up to the kernels' tile-dependent rounding."""
+        m = self.model
+        feats = [self._event_features(inp) for inp in inps]
+        seqs = [torch.cat([inp["input_ids"][0], inp["gen_token_ids"]]) for inp in inps]
+        width = max(int(q.shape[0]) for q in seqs)
+        ids = torch.zeros(len(seqs), width, dtype=torch.long)
+        mask = torch.zeros(len(seqs), width, dtype=torch.long)
+        for i, q in enumerate(seqs):
+            ids[i, :q.shape[0]] = q
+            mask[i, :q.shape[0]] = 1
+        out = m.prepare_inputs_labels_for_multimodal(
+            ids.to(self.device), None, mask.to(self.device), None, None, event_features=feats,
+            event_image_sizes=[inp["event_image_size"] for inp in inps], already_adapted=not self.double_adaptor)
+        lengths = out[2].sum(1).tolist()
+        embeds = out[4].detach().requires_grad_(True)
+        hidden = m.model(inputs_embeds=embeds, use_cache=False).last_hidden_state
+        preds = []
+        for i, inp in enumerate(inps):
+            n, end = int(inp["gen_token_ids"].shape[0]), int(lengths[i])
+            preds.append(hidden[i, end - n:end])
+        return preds
 
     def _loss(self, pred: torch.Tensor, target: torch.Tensor) -> Dict[str, torch.Tensor]:
         if self.vl_lm_head is not None:
@@ -192,22 +224,48 @@ class LoRATrainer:
         n = micro = 0
         if train:
             self.opt.zero_grad()
-        for inp, target in self._iter_samples(chunks_dir, ds):
+        buf: List = []
+
+        def flush() -> int:
+            """One forward / backward over the buffered samples; returns how many of them counted."""
+            nonlocal n
+            counted, total = 0, None
             with torch.set_grad_enabled(train):
-                pred = self.teacher_forced_forward(inp)
-                k = min(pred.shape[0], target.shape[0])
-                if k < MIN_LEN:
-                    continue
-                out = self._loss(pred[:k], target[:k].to(self.device))
-                if train:
-                    (out["total_loss"] / self.accum).backward()
-                    micro += 1
-                    if micro % self.accum == 0:
-                        self.opt.step(max_grad_norm=1.0)
-                        self.opt.zero_grad()
-            for key, v in out.items():
-                sums[key] = sums.get(key, 0.0) + float(v.detach())
-            n += 1
+                if len(buf) > 1:
+                    preds = self.teacher_forced_forward_batch([b[0] for b in buf])
+                else:
+                    preds = [self.teacher_forced_forward(buf[0][0])]
+                for pred, (_, target) in zip(preds, buf):
+                    k = min(pred.shape[0], target.shape[0])
+                    if k < MIN_LEN:
+                        continue
+                    out = self._loss(pred[:k], target[:k].to(self.device))
+                    total = out["total_loss"] if total is None else total + out["total_loss"]
+                    for key, v in out.items():
+                        sums[key] = sums.get(key, 0.0) + float(v.detach())
+                    n += 1
+                    counted += 1
+                if train and total is not None:
+                    (total / self.accum).backward()
+            buf.clear()
+            return counted
+
+        def after(counted: int) -> None:
+            nonlocal micro
+            if train and counted:
+                micro += counted
+                if micro % self.accum == 0:
+                    self.opt.step(max_grad_norm=1.0)
+                    self.opt.zero_grad()
+
+        for inp, target in self._iter_samples(chunks_dir, ds):
+            buf.append((inp, target))
+            # a batch never straddles an optimizer step: at most the samples left in the window
+            room = self.accum - micro % self.accum if train else self.micro_batch
+            if len(buf) >= min(self.micro_batch, room):
+                after(flush())
+        if buf:
+            after(flush())
         if train and micro % self.accum != 0:
             self.opt.step(max_grad_norm=1.0)
             self.opt.zero_grad()
@@ -253,6 +311,7 @@ class LoRATrainer:
             with open(os.path.join(self.output_dir, "config.json"), "w") as f:
                 json.dump({"lora": getattr(self.model, "_lora_config", {}), "parameters": self.params,
                            "learning_rate": self.lr, "gradient_accumulation": self.accum,
+                           "micro_batch": self.micro_batch,
                            "token_loss_weight": self.token_loss_weight, "event_image_key": self.key,
                            "world_size": self.info.world, "best_metric": best,
                            "created": datetime.now().isoformat()}, f, indent=2)
@@ -279,6 +338,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--learning_rate", type=float, default=1e-4)
     p.add_argument("--batch_size", type=int, default=1, help="micro-batch is one sample; use --gradient_accumulation")
     p.add_argument("--gradient_accumulation", type=int, default=16)
+    p.add_argument("--micro_batch", type=int, default=1,
+                   help="samples of an accumulation window run as one right-padded forward / backward")
     p.add_argument("--num_epochs", type=int, default=20)
     p.add_argument("--early_stopping", type=int, default=5)
     p.add_argument("--output_dir", default=None)
@@ -313,7 +374,7 @@ def main(argv=None) -> Dict:
                           args.val_dataset_dir, args.event_image_key, args.lora_rank, args.lora_alpha,
                           args.lora_dropout, args.token_loss_weight, args.learning_rate,
                           args.gradient_accumulation, args.num_epochs, args.early_stopping, out, info,
-                          not args.single_adaptor, args.max_samples, args.gradient_checkpointing)
+                          not args.single_adaptor, args.max_samples, args.gradient_checkpointing, args.micro_batch)
     if info.is_main:
         print(f"[L6] {trainer.params['trainable']:,} trainable of {trainer.params['total']:,} parameters "
               f"({trainer.params['percent']:.3f}%), {len(trainer.wrapped)} wrapped layers, world {info.world}",

@@ -74,6 +74,34 @@ def test_l6_trainer_end_to_end(tmp_path):
     assert cfg["lora"]["r"] == 4 and cfg["parameters"]["trainable"] > 0
 
 
+def test_l6_micro_batches_equal_single_sample_passes(tmp_path):
+    """``--micro_batch 2`` (two samples of an accumulation window as one right-padded pass) trains to the
+    same losses as one sample per pass: same windows, same optimizer steps, fp32 on the CPU."""
+    from eventgpt_amd.align import train_lora as TL
+    from eventgpt_amd.pipeline import dataset as D
+    from eventgpt_amd.pipeline import extract_hidden_states as X
+    data = D.make_synthetic_dataset(str(tmp_path / "ds"), n_samples=3, n_events=3000)
+    X.main(["--dataset_dir", data, "--output_dir", str(tmp_path / "hs"), "--random_init", "tiny", "--device", "cpu",
+            "--max_new_tokens", "9", "--max_questions", "2", "--chunk_size", "4", "--event_image_key",
+            "event_image_1f"])
+    store = str(tmp_path / "hs" / "chunked_train_1s_bf16")
+    torch.save({"lm_head_weight": torch.randn(320, 64)}, tmp_path / "lm.pt")
+    hist = []
+    for mb in (1, 2, 3):
+        torch.manual_seed(3)
+        res = TL.main(["--existing_chunks", store, "--dataset_dir", data, "--random_init", "tiny", "--cpu",
+                       "--num_epochs", "2", "--gradient_accumulation", "4", "--micro_batch", str(mb),
+                       "--learning_rate", "5e-3", "--lora_rank", "4", "--lora_alpha", "8", "--lora_dropout", "0.0",
+                       "--lm_head_path", str(tmp_path / "lm.pt"), "--max_questions", "2",
+                       "--output_dir", str(tmp_path / f"L6_{mb}")])
+        hist.append(res["history"])
+    for other in hist[1:]:
+        for a, b in zip(hist[0], other):
+            assert a["train_samples"] == b["train_samples"] == 6
+            for k in ("train_total_loss", "train_mse_loss", "train_cos_sim", "train_ce_loss"):
+                assert abs(a[k] - b[k]) <= 2e-4 * max(1.0, abs(a[k])), (k, a[k], b[k])
+
+
 def test_l6_sample_falls_back_to_recorded_token_ids():
     """An answer whose text decoded to "" (ids outside the tokenizer's round-trip range)
     is trained on from the drafter's recorded ids instead of being dropped."""
