@@ -539,10 +539,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 //     which no wave passes before both rows have done their wait.
 // Loads past the end of K are issued anyway: the buffer descriptor's range check turns them
 // into zero fills of images nobody reads, which keeps the vmcnt arithmetic uniform.
-template <bool AT, bool BT>
+// BMT = 128: the same schedule on a 128 x 256 tile (each wave 64 x 64; the A images are 64 rows, one staging
+// instruction per wave; 8 MFMAs per phase) for row counts that fill 256-row tiles badly.  K-contiguous A only.
+template <bool AT, bool BT, int BMT = 256>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
-  constexpr int BM = 256, BN = 256, HALF = 16384, TILE = 4 * HALF;
-  constexpr int TM = 8, TN = 4;
+  static_assert(BMT == 256 || (BMT == 128 && !AT), "128-row variant: K-contiguous A");
+  constexpr int BM = BMT, BN = 256, A_HALF = BM * 64, W_HALF = 16384, TILE = 2 * A_HALF + 2 * W_HALF;
+  constexpr int IS = BM / 64;          // 16-row tiles of one wave in one A image
+  constexpr int LA = BM / 128;         // staging instructions per wave and A image
+  constexpr int QR = BM / 4;           // rows of one wave row in one A image
+  constexpr int TM = 2 * IS, TN = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -567,10 +573,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
       const int lin = rg * 64 + lane;
       const int row = lin >> 4, cl = (lin & 15) ^ swz_t<128>(row);
       voff_a[i] = (row * p.lda + m0 + (cl >> 3) * 128 + (cl & 7) * 8) * 2;
-    } else {                 // image [128 rows][64 k]
-      const int lr = rg * 8 + (lane >> 3);
+    } else {                 // image [BM / 2 rows][64 k]: rows = two runs of QR (wave rows 0 / 1)
+      const int lr = (wid * LA + (i < LA ? i : 0)) * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((lr >> 1) & 7);
-      voff_a[i] = ((m0 + (lr >> 6) * 128 + (lr & 63)) * p.lda + c * 8) * 2;
+      voff_a[i] = ((m0 + (lr / QR) * (BM / 2) + (lr % QR)) * p.lda + c * 8) * 2;
     }
     if constexpr (BT) {      // columns = four runs of 32 (wave columns 0..3)
       const int lin = rg * 64 + lane;
@@ -587,15 +593,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   // which: 0 = A-sub0, 1 = A-sub1, 2 = W-sub0, 3 = W-sub1; kt may run past nk (zero fill)
   auto stage = [&](int which, int kt) {
     const int k0 = k_begin + kt * BK, h = which & 1;
-    unsigned char* dst = smem + (kt & 1) * TILE + which * HALF + wid * 2048;
     if (which < 2) {
-      const long long adv = AT ? 2ll * k0 * p.lda + 2ll * h * 64 : 2ll * k0 + 2ll * h * 64 * p.lda;
+      unsigned char* dst = smem + (kt & 1) * TILE + which * A_HALF + wid * (LA * 1024);
+      const long long adv = AT ? 2ll * k0 * p.lda + 2ll * h * 64 : 2ll * k0 + 2ll * h * QR * p.lda;
       const long long left = bytes_a - adv;
       const unsigned char* src = reinterpret_cast<const unsigned char*>(p.A) + adv;
       const int lim = static_cast<int>(left > 0 ? left : 0);
       buffer_to_lds16(src, lim, dst, voff_a[0]);
-      buffer_to_lds16(src, lim, dst + 1024, voff_a[1]);
+      if constexpr (LA == 2) buffer_to_lds16(src, lim, dst + 1024, voff_a[1]);
     } else {
+      unsigned char* dst = smem + (kt & 1) * TILE + 2 * A_HALF + (which - 2) * W_HALF + wid * 2048;
       const long long adv = BT ? 2ll * k0 * p.ldw + 2ll * h * 32
                                : 2ll * k0 + 2ll * h * (p.glu_half ? p.glu_half : 32) * p.ldw;
       const long long left = bytes_w - adv;
@@ -615,14 +622,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   const int frow = lane & 15, fq = lane >> 4;
   const int fsw = (frow >> 1) & 7;
   // per-lane read offsets inside an image (K-contiguous operands), one per 32-wide k-step
-  const int rd_a[2] = {(wr * 64 + frow) * 128 + ((fq ^ fsw) << 4), (wr * 64 + frow) * 128 + (((4 + fq) ^ fsw) << 4)};
+  const int rd_a[2] = {(wr * QR + frow) * 128 + ((fq ^ fsw) << 4), (wr * QR + frow) * 128 + (((4 + fq) ^ fsw) << 4)};
   const int rd_w[2] = {(wc * 32 + frow) * 128 + ((fq ^ fsw) << 4), (wc * 32 + frow) * 128 + (((4 + fq) ^ fsw) << 4)};
 
-  bf16x8_t af[2][4][2], wf[2][2][2];     // [sub][16-row tile][k-step]
+  bf16x8_t af[2][IS][2], wf[2][2][2];     // [sub][16-row tile][k-step]
   auto read_a = [&](int buf, int h) {
-    const unsigned char* img = smem + buf * TILE + h * HALF;
+    const unsigned char* img = smem + buf * TILE + h * A_HALF;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < IS; ++i)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         if constexpr (AT) af[h][i][ks] = frag_t<128>(img, wr * 64 + i * 16, ks, lane);
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
       }
   };
   auto read_w = [&](int buf, int h) {
-    const unsigned char* img = smem + buf * TILE + (2 + h) * HALF;
+    const unsigned char* img = smem + buf * TILE + 2 * A_HALF + h * W_HALF;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -644,11 +651,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < IS; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[ha * 4 + i][hw * 2 + j] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[hw][j][ks], af[ha][i][ks], acc[ha * 4 + i][hw * 2 + j], 0, 0, 0);
+          acc[ha * IS + i][hw * 2 + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[hw][j][ks], af[ha][i][ks], acc[ha * IS + i][hw * 2 + j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
   // workgroup barrier that neither the compiler's passes nor its scheduler move code across
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   // ---- prologue: tile 0 whole, then the three images of tile 1 the steady state keeps in flight
   stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
   stage(2, 1); stage(0, 1); stage(3, 1);
-  wait_vm<6>();
+  wait_vm<4 + LA>();      // the three youngest images (W, A, W) stay in flight
   fence();
   if (wr == 1) fence();
 
@@ -690,7 +697,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     fence();
     // phase 4
     stage(3, kt + 2);
-    wait_vm<6>();
+    wait_vm<4 + LA>();
     fence();
     mma(1, 0);
     fence();
@@ -702,24 +709,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   if (wr == 0) fence();
   wait_vm<0>();   // zero fills past K must have landed before the workgroup's LDS is handed on
 
-  gemm_epilogue<TM, TN, 128, 64, 4>(p, acc, m0, n0, wr, wc, tn, tiles_n, ksplit, lane);
+  gemm_epilogue<TM, TN, BM / 2, 64, 4>(p, acc, m0, n0, wr, wc, tn, tiles_n, ksplit, lane);
 }
 
 static bool g_use_256 = true;
 void gemm_enable_256(bool on) { g_use_256 = on; }
 
-template <bool AT, bool BT>
+template <bool AT, bool BT, int BM = 256>
 static void launch_256(const GemmParams& p, hipStream_t st) {
   const int bn_out = p.glu_half ? 128 : 256;
-  const int tiles = ((p.M + 255) / 256) * ((p.N + bn_out - 1) / bn_out) * p.splitk;
-  constexpr int smem = 128 * 1024;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + bn_out - 1) / bn_out) * p.splitk;
+  constexpr int smem = 2 * (2 * BM * 64 + 2 * 16384);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<AT, BT>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<AT, BT, BM>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256_kernel<AT, BT>), dim3(tiles), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((gemm256_kernel<AT, BT, BM>), dim3(tiles), dim3(512), smem, st, p);
 }
 
 // out = act(sum_s partial[s] + bias) + res, 4 columns per thread
@@ -773,7 +780,8 @@ static void launch_cfg(const GemmParams& p, hipStream_t st) {
 // CUs; shapes that cannot (prefill of a few hundred rows against a 1024- or
 // 4096-wide matrix, verify batches) take smaller tiles with a deeper ring, since
 // a grid below one block per CU is bound by the latency of its own K loop.
-enum GemmCfg { CFG_128x128 = 0, CFG_64x128 = 1, CFG_64x64 = 2, CFG_32x64 = 3, CFG_32x128 = 4, CFG_256x256 = 5 };
+enum GemmCfg { CFG_128x128 = 0, CFG_64x128 = 1, CFG_64x64 = 2, CFG_32x64 = 3, CFG_32x128 = 4, CFG_256x256 = 5,
+               CFG_128x256 = 6 };
 
 static int g_forced_cfg = -1;
 void gemm_force_config(int cfg) { g_forced_cfg = cfg; }
@@ -832,7 +840,7 @@ static GemmCfg pick_cfg(int M, int N, int K = 0) {
 }
 
 static long long cfg_tiles(GemmCfg c, int M, int N) {
-  static const int bm[] = {128, 64, 64, 32, 32, 256}, bn[] = {128, 128, 64, 64, 128, 256};
+  static const int bm[] = {128, 64, 64, 32, 32, 256, 128}, bn[] = {128, 128, 64, 64, 128, 256, 256};
   return static_cast<long long>((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]);
 }
 
@@ -927,7 +935,7 @@ void gemm_enable_tail_splitk(bool on) { g_tail_splitk = on; }
 
 int gemm_argmax_partials(int M, int N) {
   switch (pick_cfg(M, N)) {  // tiles_n * WGN of the chosen config
-    case CFG_256x256: return ((N + 255) / 256) * 4;
+    case CFG_256x256: case CFG_128x256: return ((N + 255) / 256) * 4;
     case CFG_128x128: case CFG_64x128: return ((N + 127) / 128) * 2;
     case CFG_64x64: return ((N + 63) / 64) * 2;
     case CFG_32x64: return ((N + 63) / 64) * 4;
@@ -1006,6 +1014,7 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
     case CFG_64x64: launch_cfg<64, 64, 2, 2, 4>(p, st); break;
     case CFG_32x64: launch_cfg<32, 64, 1, 4, 4>(p, st); break;
     case CFG_256x256: launch_256<false, false>(p, st); break;
+    case CFG_128x256: launch_256<false, false, 128>(p, st); break;
     default: launch_cfg<32, 128, 1, 4, 4>(p, st); break;
   }
   if (p.splitk > 1) {
@@ -1153,6 +1162,7 @@ int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M,
     case CFG_64x64: launch_cfg<64, 64, 2, 2, 4>(p, st); break;
     case CFG_32x64: launch_cfg<32, 64, 1, 4, 4>(p, st); break;
     case CFG_256x256: launch_256<false, false>(p, st); break;
+    case CFG_128x256: launch_256<false, false, 128>(p, st); break;
     default: launch_cfg<32, 128, 1, 4, 4>(p, st); break;
   }
   return p.splitk;

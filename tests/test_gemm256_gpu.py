@@ -187,3 +187,36 @@ def test_swiglu_gemm_last_tiles_on_small_tiles(dev, M, I, K):
         raw.gemm_enable_tail_splitk(True)
     _check(y, want, K)
     assert torch.allclose(y.float(), one.float(), atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 256, 64), (128, 256, 192), (636, 4096, 4096), (636, 12288, 4096), (300, 264, 320),
+                                   (1000, 520, 1024), (37, 4096, 512)])
+def test_forced_128_row_variant_matches_fp32(dev, M, N, K):
+    """The 8-phase schedule on a 128 x 256 tile (config 6): values, determinism, bias / activation / residual
+    epilogue, an identity operand against an asymmetric one, and K split over its slabs."""
+    from eventgpt_amd.ops import hip
+    raw = hip.raw
+    x, w = _rand(M, K, dev=dev), _rand(N, K, dev=dev, seed=1, scale=0.05)
+    want = x.float() @ w.float().t()
+    raw.gemm_force_config(6)
+    try:
+        first = None
+        for rep in range(3):
+            y = raw.linear(x, w, None, None, 0, False)
+            _check(y, want, K)
+            first = y if first is None else first
+            assert torch.equal(y, first), rep
+        bias, res = _rand(N, dev=dev, seed=2), _rand(M, N, dev=dev, seed=3)
+        y = raw.linear(x, w, bias, res, 1, False)
+        _check(y, torch.nn.functional.gelu(want + bias.float()).to(torch.bfloat16).float() + res.float(), K)
+        if K >= 1024:
+            raw.gemm_force_splitk(2)
+            _check(raw.linear(x, w, None, None, 0, False), want, K)
+            raw.gemm_force_splitk(0)
+        n = 256
+        eye = torch.eye(n, device=dev, dtype=torch.bfloat16)
+        wa = (torch.arange(n * 520, device=dev).reshape(520, n) % 251).to(torch.bfloat16)
+        assert torch.equal(raw.linear(eye, wa, None, None, 0, False), wa.t())
+    finally:
+        raw.gemm_force_splitk(0)
+        raw.gemm_force_config(-1)
