@@ -307,6 +307,30 @@ std::tuple<Tensor, Tensor> reduce_residual_norm(const Tensor& partial, const c10
   return {x, xn};
 }
 
+// x = bf16(sum partial + bias) + res; y = LayerNorm(x) * ln_w + ln_b when ln_w is given (else an empty tensor).
+// Rows of up to 2048 elements.
+std::tuple<Tensor, Tensor> reduce_residual_layernorm(const Tensor& partial, const c10::optional<Tensor>& bias,
+                                                     const c10::optional<Tensor>& res,
+                                                     const c10::optional<Tensor>& ln_w,
+                                                     const c10::optional<Tensor>& ln_b, double eps) {
+  check_f32(partial, "partial");
+  TORCH_CHECK(partial.dim() == 3, "partial must be [nslab, M, N]");
+  const int64_t S = partial.size(0), M = partial.size(1), N = partial.size(2);
+  TORCH_CHECK(N % 8 == 0 && N <= 2048 && M >= 1 && S >= 1, "reduce_residual_layernorm: N % 8 == 0, N <= 2048");
+  auto bf = partial.options().dtype(at::kBFloat16);
+  if (bias.has_value()) { check_bf16(*bias, "bias"); TORCH_CHECK(bias->numel() == N); }
+  if (res.has_value()) { check_bf16(*res, "res"); TORCH_CHECK(res->numel() == M * N); }
+  if (ln_w.has_value()) { check_bf16(*ln_w, "ln_w"); TORCH_CHECK(ln_w->numel() == N); }
+  if (ln_b.has_value()) { check_bf16(*ln_b, "ln_b"); TORCH_CHECK(ln_b->numel() == N && ln_w.has_value()); }
+  Tensor x = at::empty({M, N}, bf);
+  Tensor y = ln_w.has_value() ? at::empty({M, N}, bf) : at::empty({0}, bf);
+  const bool ok = evgpt::launch_reduce_residual_layernorm(
+      partial.data_ptr<float>(), (int)S, (int)M, (int)N, bptr_opt(bias), bptr_opt(res), bptr_mut(x), bptr_opt(ln_w),
+      bptr_opt(ln_b), ln_w.has_value() ? bptr_mut(y) : nullptr, (float)eps, cur_stream());
+  TORCH_CHECK(ok, "reduce_residual_layernorm: row too wide");
+  return {x, y};
+}
+
 Tensor reduce_swiglu(const Tensor& partial) {
   check_f32(partial, "partial");
   TORCH_CHECK(partial.dim() == 3 && partial.size(2) % 16 == 0, "partial must be [nslab, M, 2I]");
@@ -1325,6 +1349,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("linear_rows_(Tensor x, Tensor w, Tensor(a!) out, bool accumulate) -> ()", &linear_rows_);
   m.def("linear_t(Tensor a, Tensor w, bool a_t, bool w_t, Tensor? bias, Tensor? res, int act, bool out_f32, int K, Tensor(a!)? out=None) -> Tensor", &linear_t);
   m.def("gemv_max_batch() -> int", []() -> int64_t { return evgpt::gemv_max_batch(); });
+  m.def("reduce_residual_layernorm(Tensor partial, Tensor? bias, Tensor? res, Tensor? ln_w, Tensor? ln_b, float eps) -> (Tensor, Tensor)", &reduce_residual_layernorm);
   m.def("reduce_residual_norm(Tensor partial, Tensor? res, Tensor? norm_w, float eps, Tensor(a!)? out) -> (Tensor, Tensor)", &reduce_residual_norm);
   m.def("reduce_swiglu(Tensor partial) -> Tensor", &reduce_swiglu);
   m.def("reduce_rope_kv(Tensor partial, Tensor(a!) q_out, Tensor(b!) k_cache, Tensor(c!) v_cache, Tensor cos, Tensor sin, Tensor pos0, int B, int S, int Hq, int Hkv, int D) -> ()", &reduce_rope_kv);

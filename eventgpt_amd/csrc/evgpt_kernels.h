@@ -198,6 +198,9 @@ void launch_row_metrics_bf16(const bf16_t* a, const bf16_t* b, float* cos_out, f
                              long long rows, int H, float eps, hipStream_t st, float* stats = nullptr);
 void launch_row_affine_grad(const void* p, const void* t, const float* coef, void* grad, long long rows, int H,
                             bool bf16, hipStream_t st);
+bool launch_reduce_residual_layernorm(const float* partial, int nslab, int M, int N, const bf16_t* bias,
+                                      const bf16_t* res, bf16_t* x_out, const bf16_t* ln_w, const bf16_t* ln_b,
+                                      bf16_t* y_out, float eps, hipStream_t st);
 void launch_reduce_swiglu(const float* partial, int nslab, long long M, int I, bf16_t* out,
                           hipStream_t st);
 void launch_reduce_rope_kv(const float* partial, int nslab, bf16_t* q_out, bf16_t* k_cache,

@@ -102,6 +102,86 @@ __global__ __launch_bounds__(256) void reduce_residual_norm_kernel(
   }
 }
 
+// x_out[m] = bf16(sum + bias) + res[m];  y_out[m] = LayerNorm(x_out[m]) * ln_w + ln_b  (if ln_w): the
+// consumer of a ViT block's out-projection and second MLP projection (bias and residual of the projection,
+// then the LayerNorm the next projection reads).  One wave per row of up to 64 * 8 * NC elements; the row
+// stays in registers between the statistics and the normalisation (as layernorm_wave_kernel).
+template <int NS, int NC>
+__global__ __launch_bounds__(256) void reduce_residual_layernorm_kernel(
+    const float* __restrict__ partial, int nslab, int M, int N, const bf16_t* __restrict__ bias, const bf16_t* res,
+    bf16_t* x_out, const bf16_t* __restrict__ ln_w, const bf16_t* __restrict__ ln_b, bf16_t* __restrict__ y_out,
+    float eps) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const size_t slab = static_cast<size_t>(M) * N, base = static_cast<size_t>(m) * N;
+  const int nchunk = N >> 3;
+  u32x4_t v[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c >= nchunk) { v[i] = u32x4_t{0, 0, 0, 0}; continue; }
+    const size_t e0 = base + c * 8;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int ns = NS ? NS : nslab;
+#pragma unroll
+    for (int sidx = 0; sidx < (NS ? NS : 1); ++sidx) {
+      for (int s2 = sidx; s2 < ns; s2 += (NS ? NS : 1)) {
+        const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(partial + s2 * slab + e0);
+        const f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(partial + s2 * slab + e0 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] += t0[j]; a[4 + j] += t1[j]; }
+      }
+    }
+    if (bias) {
+      const u32x4_t bv = load16(bias + c * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[2 * j] += bf16lo(bv[j]); a[2 * j + 1] += bf16hi(bv[j]); }
+    }
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(a[2 * j], a[2 * j + 1]);
+    if (res) {
+      const u32x4_t r = load16(res + e0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(bf16lo(o[j]) + bf16lo(r[j]), bf16hi(o[j]) + bf16hi(r[j]));
+    }
+    *reinterpret_cast<u32x4_t*>(x_out + e0) = o;
+    v[i] = o;
+  }
+  if (!ln_w) return;   // wave-uniform
+  float sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm += bf16lo(v[i][j]) + bf16hi(v[i][j]);
+  const float mean = wave_sum(sm) / static_cast<float>(N);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    if (lane + 64 * i < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = bf16lo(v[i][j]) - mean, hi = bf16hi(v[i][j]) - mean;
+        ss += lo * lo + hi * hi;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / static_cast<float>(N) + eps);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c >= nchunk) continue;
+    const u32x4_t g = load16(ln_w + c * 8);
+    const u32x4_t bb = ln_b ? load16(ln_b + c * 8) : u32x4_t{0, 0, 0, 0};
+    u32x4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = pack_bf16x2((bf16lo(v[i][j]) - mean) * rstd * bf16lo(g[j]) + bf16lo(bb[j]),
+                         (bf16hi(v[i][j]) - mean) * rstd * bf16hi(g[j]) + bf16hi(bb[j]));
+    *reinterpret_cast<u32x4_t*>(y_out + base + c * 8) = o;
+  }
+}
+
 // partial [nslab][M][2I] laid out [gate | up] -> out [M][I]
 template <int NS>
 __global__ __launch_bounds__(256) void reduce_swiglu_kernel(const float* __restrict__ partial,
@@ -292,6 +372,26 @@ void launch_reduce_residual_norm(const float* partial, int nslab, int M, int N, 
                      N, res, x_out, norm_w, xn_out, eps)
   EVGPT_NSLAB_SWITCH(nslab, L_)
 #undef L_
+}
+
+// N <= 2048 (a multiple of 8); returns false for wider rows (nothing launched)
+bool launch_reduce_residual_layernorm(const float* partial, int nslab, int M, int N, const bf16_t* bias,
+                                      const bf16_t* res, bf16_t* x_out, const bf16_t* ln_w, const bf16_t* ln_b,
+                                      bf16_t* y_out, float eps, hipStream_t st) {
+  const int nchunk = N >> 3;
+  if (nchunk > 256 || M < 1) return false;
+#define L_(NS)                                                                                                      \
+  do {                                                                                                              \
+    if (nchunk <= 128)                                                                                              \
+      hipLaunchKernelGGL((reduce_residual_layernorm_kernel<NS, 2>), dim3((M + 3) / 4), dim3(256), 0, st, partial,  \
+                         nslab, M, N, bias, res, x_out, ln_w, ln_b, y_out, eps);                                    \
+    else                                                                                                            \
+      hipLaunchKernelGGL((reduce_residual_layernorm_kernel<NS, 4>), dim3((M + 3) / 4), dim3(256), 0, st, partial,  \
+                         nslab, M, N, bias, res, x_out, ln_w, ln_b, y_out, eps);                                    \
+  } while (0)
+  EVGPT_NSLAB_SWITCH(nslab, L_)
+#undef L_
+  return true;
 }
 
 void launch_reduce_swiglu(const float* partial, int nslab, long long M, int I, bf16_t* out,

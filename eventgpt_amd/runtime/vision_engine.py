@@ -90,6 +90,9 @@ class VisionEngine:
         self.adaptor = (fa.weight.data, fa.bias.data) if fa is not None else None
         self._graphs: Dict[tuple, tuple] = {}
 
+    # bias + residual + the next LayerNorm inside the split-K slab sum of out-proj / fc2 (see _forward)
+    fuse_norms = True
+
     # ------------------------------------------------------------------ forward
     def _forward(self, px: torch.Tensor, pool: bool, n_temporal: Optional[int],
                  tower_only: bool = False) -> torch.Tensor:
@@ -102,15 +105,34 @@ class VisionEngine:
         x = raw.vit_embed_ln(tok.view(T, n - 1, d), self.cls, self.pos, self.pre_ln[0],
                              self.pre_ln[1], self.eps)
         scale = hd ** -0.5
-        for l in self.layers:
-            y = raw.layernorm(x, l["ln1"][0], l["ln1"][1], self.eps)
-            qkv = raw.linear(y, l["w_qkv"], l["b_qkv"], None, 0, False).view(T, n, 3, H, hd)
-            o = raw.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], False, scale, 0)
-            x = raw.linear(o.view(T, n, d), l["w_o"], l["b_o"], x, 0, False)
-            y = raw.layernorm(x, l["ln2"][0], l["ln2"][1], self.eps)
-            y = raw.linear(y, l["w1"], l["b1"], None, self.act, False)
-            x = raw.linear(y, l["w2"], l["b2"], x, 0, False)
-        f = x
+        inter = self.cfg.intermediate_size
+        if self.fuse_norms and d <= 2048 and inter % 64 == 0:
+            # The two row-parallel projections of a block stop at their fp32 split-K slabs, and the kernel that
+            # sums them also adds bias and residual and applies the LayerNorm the next projection reads:
+            # 5 launches per block (qkv, attention, out-proj, fc1, fc2 + two consumers = 7 with them) instead of
+            # 7 plus a split-K reduction, and the narrow out-projection may split its contraction too.
+            x = x.view(T * n, d)
+            y = raw.layernorm(x, self.layers[0]["ln1"][0], self.layers[0]["ln1"][1], self.eps)
+            for i, l in enumerate(self.layers):
+                qkv = raw.linear(y, l["w_qkv"], l["b_qkv"], None, 0, False).view(T, n, 3, H, hd)
+                o = raw.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], False, scale, 0)
+                x, y = raw.reduce_residual_layernorm(raw.linear_partial(o.view(T * n, d), l["w_o"]), l["b_o"], x,
+                                                     l["ln2"][0], l["ln2"][1], self.eps)
+                y = raw.linear(y, l["w1"], l["b1"], None, self.act, False)
+                nxt = self.layers[i + 1]["ln1"] if i + 1 < len(self.layers) else (None, None)
+                x, y = raw.reduce_residual_layernorm(raw.linear_partial(y, l["w2"]), l["b2"], x, nxt[0], nxt[1],
+                                                     self.eps)
+            f = x.view(T, n, d)
+        else:
+            for l in self.layers:
+                y = raw.layernorm(x, l["ln1"][0], l["ln1"][1], self.eps)
+                qkv = raw.linear(y, l["w_qkv"], l["b_qkv"], None, 0, False).view(T, n, 3, H, hd)
+                o = raw.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], False, scale, 0)
+                x = raw.linear(o.view(T, n, d), l["w_o"], l["b_o"], x, 0, False)
+                y = raw.layernorm(x, l["ln2"][0], l["ln2"][1], self.eps)
+                y = raw.linear(y, l["w1"], l["b1"], None, self.act, False)
+                x = raw.linear(y, l["w2"], l["b2"], x, 0, False)
+            f = x
         if tower_only:
             return f
         for i, (w, b) in enumerate(self.proj):

@@ -524,3 +524,42 @@ def test_engine_first_used_under_inference_mode_works_outside_it(dev):
     c = eng.generate(emb, 8, eos_token_id=-1)
     _ = torch.randn(8, device=dev)
     assert torch.equal(a.clone(), b) and torch.equal(b, c)
+
+
+@pytest.mark.parametrize("M,N,ns", [(577, 1024, 3), (70, 256, 1), (2885, 1024, 1), (33, 2048, 2), (5, 264, 5)])
+def test_slab_sum_with_bias_residual_and_layernorm(dev, M, N, ns):
+    """The consumer of a ViT block's row-parallel projections: bf16(sum of slabs + bias) + residual, and the
+    LayerNorm of that row, against fp32 arithmetic with the same rounding points."""
+    raw = torch.ops.evgpt
+    g = torch.Generator(device=dev).manual_seed(M + N)
+    part = torch.randn(ns, M, N, device=dev, generator=g)
+    bias = torch.randn(N, device=dev, generator=g).to(torch.bfloat16)
+    res = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(N, device=dev, generator=g)).to(torch.bfloat16)
+    b = (0.1 * torch.randn(N, device=dev, generator=g)).to(torch.bfloat16)
+    x, y = raw.reduce_residual_layernorm(part, bias, res, w, b, 1e-5)
+    want_x = ((part.sum(0) + bias.float()).to(torch.bfloat16).float() + res.float()).to(torch.bfloat16)
+    assert (x.float() - want_x.float()).abs().max().item() <= 2.0 ** -6 * float(want_x.float().abs().max())
+    want_y = torch.nn.functional.layer_norm(x.float(), (N,), w.float(), b.float(), 1e-5)
+    assert (y.float() - want_y).abs().max().item() < 0.03
+    x2, y2 = raw.reduce_residual_layernorm(part, None, None, None, None, 1e-5)
+    assert y2.numel() == 0 and (x2.float() - part.sum(0)).abs().max().item() <= 2.0 ** -7 * float(part.sum(0).abs().max())
+
+
+def test_vision_engine_fused_norms_equal_separate_kernels(dev):
+    """ViT blocks with bias + residual + next LayerNorm inside the slab sum against one kernel per op."""
+    from eventgpt_amd.models import ClipVisionConfig
+    from eventgpt_amd.runtime.vision_engine import VisionEngine
+    cfg = EventChatConfig(vocab_size=1003, hidden_size=512, intermediate_size=1408, num_hidden_layers=1,
+                          num_attention_heads=4, mm_visual_tower="t", event_feature_adaptor=True)
+    cfg.vision_config = ClipVisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=4,
+                                         num_attention_heads=4, image_size=56, patch_size=14)
+    m = EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=4)
+    frames = torch.randn(3, 3, 56, 56, device=dev).to(torch.bfloat16)
+    fused, plain = VisionEngine(m), VisionEngine(m)
+    plain.fuse_norms = False
+    a, b = fused.encode(frames, pool=False), plain.encode(frames, pool=False)
+    assert a.shape == b.shape
+    cos = torch.nn.functional.cosine_similarity(a.float().flatten(1), b.float().flatten(1), dim=1)
+    assert float(cos.min()) > 0.9995 and (a.float() - b.float()).abs().max().item() < 0.04 * float(b.float().abs().max())
+    assert torch.equal(fused.encode(frames, pool=False), a)          # graph replay
