@@ -432,15 +432,23 @@ class TensorParallelEngine(GenerationEngine):
             return self._forward_rows_gemv(embeds, batch, pos0)
         if self._few_rows_ok(S):
             return self._forward_rows_fused(embeds, batch, pos0)
+        if self.tp_world == 1:
+            return super()._forward_rows(embeds, batch, pos0)      # one rank: the single-GPU prompt path
         x = embeds.to(torch.bfloat16).contiguous().view(1, S, self.H)
         kv_len = pos0 + S
         q = torch.empty(1, S, self.Hq, self.D, dtype=torch.bfloat16, device=self.device)
         o = torch.empty_like(q)
         lead = self.tp_rank == 0
+        rope_gemm = self.D == 128 and S <= self.prompt_fused_rows and self.H % 64 == 0
         for l in self.layers:
             kc, vc = l.k_cache[batch:batch + 1], l.v_cache[batch:batch + 1]
-            qkv = raw.linear(raw.rmsnorm(x, l.norm1, self.eps), l.w_qkv, None, None, 0, False)
-            raw.prefill_rope_kv(qkv, q, kc, vc, self.cos, self.sin, pos0, self.Hq, self.Hkv, self.D)
+            xn = raw.rmsnorm(x, l.norm1, self.eps).view(S, self.H)
+            # this rank's heads: RoPE + cache append in the projection's epilogue where the tile allows it
+            if not (rope_gemm and raw.linear_qkv_rope(xn, l.w_qkv, q, kc, vc, self.cos, self.sin, pos0,
+                                                      self.Hq, self.Hkv)):
+                rope_gemm = False
+                qkv = raw.linear(xn, l.w_qkv, None, None, 0, False).view(1, S, -1)
+                raw.prefill_rope_kv(qkv, q, kc, vc, self.cos, self.sin, pos0, self.Hq, self.Hkv, self.D)
             raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
             x = self._reduce(raw.linear(o.view(1, S, self.Hq * self.D), l.w_o, None,
                                         x if lead else None, 0, False))
