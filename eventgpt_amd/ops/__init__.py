@@ -106,11 +106,10 @@ def lowrank_delta(x, a, b, scale: float):
 def lora_projection(x, weight, adapters, scale: float, drop_p: float = 0.0, residual=None):
     """``x W^T (+ residual)`` of a frozen projection with low-rank adapters ``[(column offset, A, B), ...]`` on
     column ranges of its output and input dropout ``drop_p`` per adapter, as ONE autograd node on the
-    in-tree kernels (``ops.differentiable._LoRAProjection``) -- or None when that node does not take these
-    operands (CPU tensors, other dtypes, a trainable base, nothing to record): the caller then composes the
-    same thing from ``linear`` / ``lowrank_delta`` / ``add_column_blocks``."""
-    flat = [t for _, a, b in adapters for t in (a, b)]
-    if adapters and _train(x, weight, residual, *flat) and _diff().lora_projection_ok(x, weight, adapters, residual):
+    in-tree kernels (``ops.differentiable._LoRAProjection``; the same launches unrecorded when autograd is off)
+    -- or None when those kernels do not take these operands (CPU tensors, other dtypes, a trainable base):
+    the caller then composes the same thing from ``linear`` / ``lowrank_delta`` / ``add_column_blocks``."""
+    if adapters and x.is_cuda and _diff().lora_projection_ok(x, weight, adapters, residual):
         return _diff().lora_projection(x, weight, adapters, scale, drop_p, residual)
     return None
 

@@ -554,6 +554,29 @@ class _LowRank(torch.autograd.Function):
         return dx, da, db, None
 
 
+def _lora_projection_forward(x, weight, residual, scale, drop_p, offsets, ab):
+    """The forward launches of ``_LoRAProjection``: ``(y, x as rows, rank-r intermediates, seeds)``.  One seed per
+    adapter is drawn from torch's CPU generator, in adapter order, whether or not autograd records the call --
+    so a block that is recomputed under activation checkpointing (which restores that generator) sees the
+    masks of its first pass."""
+    from . import hip
+    raw = _raw()
+    k = x.shape[-1]
+    xc = x if x.is_contiguous() else x.contiguous()
+    x2 = xc.view(-1, k)
+    y = hip.linear(xc, weight, None, None, residual)
+    y2 = y.view(-1, y.shape[-1])
+    ts, seeds = [], []
+    for i, off in enumerate(offsets):
+        a, b = ab[2 * i], ab[2 * i + 1]
+        seed = next_seed() if drop_p > 0 else 0
+        t = raw.lowrank_out(x2, a, scale, drop_p, seed)                  # [M, r], scale / (1 - p) applied
+        raw.linear_rows_(t, b, y2[:, off:off + b.shape[0]], True)
+        ts.append(t)
+        seeds.append(seed)
+    return y, x2, ts, seeds
+
+
 class _LoRAProjection(torch.autograd.Function):
     """``y = x W^T (+ residual)`` of a FROZEN projection with low-rank adapters on column ranges of its output
     (one adapter on all columns of an ``o_proj``; three on the q / k / v ranges of a grouped projection):
@@ -571,21 +594,7 @@ class _LoRAProjection(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, residual, scale, drop_p, offsets, *ab):
-        from . import hip
-        raw = _raw()
-        k = x.shape[-1]
-        xc = x if x.is_contiguous() else x.contiguous()
-        x2 = xc.view(-1, k)
-        y = hip.linear(xc, weight, None, None, residual)
-        y2 = y.view(-1, y.shape[-1])
-        ts, seeds = [], []
-        for i, off in enumerate(offsets):
-            a, b = ab[2 * i], ab[2 * i + 1]
-            seed = next_seed() if drop_p > 0 else 0
-            t = raw.lowrank_out(x2, a, scale, drop_p, seed)                  # [M, r], scale / (1 - p) applied
-            raw.linear_rows_(t, b, y2[:, off:off + b.shape[0]], True)
-            ts.append(t)
-            seeds.append(seed)
+        y, x2, ts, seeds = _lora_projection_forward(x, weight, residual, scale, drop_p, offsets, ab)
         ctx.save_for_backward(x2, weight, *ts, *ab)
         ctx.meta = (float(scale), float(drop_p), tuple(offsets), tuple(seeds))
         return y
@@ -665,10 +674,15 @@ def lora_projection_ok(x, weight, adapters, residual=None) -> bool:
 
 def lora_projection(x, weight, adapters, scale: float, drop_p: float = 0.0, residual=None):
     """``x W^T (+ residual)`` with low-rank updates ``adapters = [(column offset, A [r, K], B [n, r]), ...]`` on
-    column ranges of the output, input dropout ``drop_p`` per adapter (pass 0 outside training)."""
+    column ranges of the output, input dropout ``drop_p`` per adapter (pass 0 outside training).  Outside
+    autograd (evaluation, or the first pass of a checkpointed block) the same kernels run unrecorded."""
     flat = [t for _, a, b in adapters for t in (a, b)]
-    return _LoRAProjection.apply(x, weight, residual, float(scale), float(drop_p),
-                                 tuple(int(off) for off, _, _ in adapters), *flat)
+    offsets = tuple(int(off) for off, _, _ in adapters)
+    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, residual, *flat))):
+        with torch.no_grad():
+            return _lora_projection_forward(x, weight, residual, float(scale), float(drop_p), offsets,
+                                            [t.detach() for t in flat])[0]
+    return _LoRAProjection.apply(x, weight, residual, float(scale), float(drop_p), offsets, *flat)
 
 
 def lowrank_delta(x, a, b, scale: float):

@@ -521,3 +521,23 @@ def test_linear_with_residual_is_one_node(dev):
     assert torch.equal(r.grad, go)
     _close(x.grad, go.float() @ w.detach().float(), 3e-2, 2e-2)
     _close(w.grad, go.float().view(-1, 1024).t() @ x.detach().float().view(-1, 512), 0.1, 2e-2)
+
+
+def test_lora_projection_same_masks_with_and_without_autograd(dev):
+    """The unrecorded pass (evaluation, or the first pass of a checkpointed block) runs the same kernels and
+    draws the same seeds as the recorded one: with the CPU generator restored the outputs are identical."""
+    from eventgpt_amd import ops
+    K, N, r = 512, 768, 16
+    x = _rand(3, 40, K, dev=dev)
+    w = _rand(N, K, dev=dev, seed=1, scale=K ** -0.5)
+    ads = [(0, _rand(r, K, dev=dev, seed=2, scale=0.05).requires_grad_(True), _rand(512, r, dev=dev, seed=3, scale=0.05).requires_grad_(True)),
+           (512, _rand(r, K, dev=dev, seed=4, scale=0.05).requires_grad_(True), _rand(256, r, dev=dev, seed=5, scale=0.05).requires_grad_(True))]
+    torch.manual_seed(11)
+    with torch.no_grad():
+        y0 = ops.lora_projection(x, w, ads, 2.0, 0.2)
+    torch.manual_seed(11)
+    y1 = ops.lora_projection(x, w, ads, 2.0, 0.2)
+    assert y0 is not None and not y0.requires_grad and y1.requires_grad
+    assert torch.equal(y0, y1.detach())
+    torch.manual_seed(12)
+    assert not torch.equal(ops.lora_projection(x, w, ads, 2.0, 0.2).detach(), y0)     # another seed, another mask
