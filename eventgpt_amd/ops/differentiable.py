@@ -604,9 +604,10 @@ class _LoRAProjection(torch.autograd.Function):
         raw = _raw()
         scale, p, offsets, seeds = ctx.meta
         n_ad = len(offsets)
-        x2, weight = ctx.saved_tensors[:2]
-        ts = ctx.saved_tensors[2:2 + n_ad]
-        ab = ctx.saved_tensors[2 + n_ad:]
+        saved = ctx.saved_tensors            # read once: activation checkpointing unpacks on access
+        x2, weight = saved[:2]
+        ts = saved[2:2 + n_ad]
+        ab = saved[2 + n_ad:]
         ntot = weight.shape[0]
         g2 = gy.reshape(-1, ntot)
         g2 = g2 if g2.is_contiguous() else g2.contiguous()
