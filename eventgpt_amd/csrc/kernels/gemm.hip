@@ -666,6 +666,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
+  // The barrier that opens a phase's MFMA part.  The fragments read in this phase are needed only after it, so
+  // their latency is spent in the barrier: the wait for them follows it.  Only reads of an image that is
+  // re-staged in the NEXT phase have to be back before the barrier (the staging row passes it before it
+  // issues): KEEP = how many of the youngest reads may still be in flight there (-1: none need to be back).
+  auto open_mma = [&](auto keep_c) {
+    constexpr int KEEP = decltype(keep_c)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (KEEP == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else if constexpr (KEEP == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    else if constexpr (KEEP == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // reads of A issued after the reads of W in phase 1 (K-contiguous A: one ds_read_b128 per fragment)
+  constexpr int A_READS = AT ? 0 : IS * 2;
 
   // ---- prologue: tile 0 whole, then the three images of tile 1 the steady state keeps in flight
   stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
@@ -676,23 +692,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 
   auto tile_body = [&](auto buf_c, int kt) {
     constexpr int buf = decltype(buf_c)::value;
-    // phase 1
+    // phase 1: W-sub0 is re-staged in phase 2, so its reads (issued first) are back before the barrier
     read_w(buf, 0);
+    __builtin_amdgcn_sched_barrier(0);
     read_a(buf, 0);
     stage(1, kt + 1);
-    fence();
+    open_mma(std::integral_constant<int, A_READS>{});
     mma(0, 0);
     fence();
-    // phase 2
+    // phase 2 (W-sub1 is re-staged in phase 4)
     read_w(buf, 1);
     stage(2, kt + 2);
-    fence();
+    open_mma(std::integral_constant<int, -1>{});
     mma(0, 1);
     fence();
-    // phase 3
+    // phase 3 (A-sub1 is re-staged in phase 1 of the next tile)
     read_a(buf, 1);
     stage(0, kt + 2);
-    fence();
+    open_mma(std::integral_constant<int, -1>{});
     mma(1, 1);
     fence();
     // phase 4
