@@ -120,6 +120,37 @@ __device__ __forceinline__ void unit_rows(const GemvParams& p, int u, int (&row)
   }
 }
 
+// The same maps for RR rows per unit (RR / 2 rotate-half or gate / up pairs): RR = 4 gives unit_rows.
+template <int E, int RR>
+__device__ __forceinline__ void unit_rows_n(const GemvParams& p, int u, int (&row)[RR]) {
+  constexpr int NP = RR / 2;
+  if constexpr (E == E_SWIGLU) {
+    static_assert(RR % 2 == 0, "gate / up pairs");
+    const int half = p.N >> 1;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { row[i] = NP * u + i; row[NP + i] = half + NP * u + i; }
+  } else if constexpr (E == E_QKV_ROPE) {
+    static_assert(RR % 2 == 0, "rotate-half pairs");
+    const int hd = p.head_dim, hh = hd >> 1;
+    const int rot_rows = (p.n_q_heads + p.n_kv_heads) * hd;
+    const int rot_units = rot_rows / RR;
+    if (u < rot_units) {
+      const int units_per_head = hh / NP;
+      const int h = u / units_per_head, j = (u % units_per_head) * NP;
+      const int base = h * hd;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) { row[i] = base + j + i; row[NP + i] = base + hh + j + i; }
+    } else {
+      const int r0 = rot_rows + (u - rot_units) * RR;
+#pragma unroll
+      for (int r = 0; r < RR; ++r) row[r] = r0 + r;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RR; ++r) row[r] = RR * u + r;
+  }
+}
+
 // x chunk i (16 bytes) sits at this slot of the LDS image.  Q = 1 lanes read chunks
 // 4c..4c+3 of consecutive c: the XOR spreads a 16-lane group over all 64 banks.
 template <int Q>
@@ -632,8 +663,14 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, Q ? (B <= 2 ? 4 : 3) : (B == 1 ? E
 #ifndef EVGPT_ROW1_OCC
 #define EVGPT_ROW1_OCC 1      // blocks per CU the register budget must admit (1: no cap)
 #endif
-template <int P, int E, int KS>
+// RR: rows per unit.  The 4096-row residual projections (o_proj, down_proj) are 1024 one-unit blocks at four
+// rows per unit -- all resident at once, every block's reduce / store tail exposed at the end of the launch;
+// two rows per unit (plain row order only) make 2048 blocks of half the work.
+template <int P, int E, int KS, int RR = 4>
 __global__ __launch_bounds__(GEMV_WAVES * 64, EVGPT_ROW1_OCC) void gemv_row1_kernel(GemvParams p) {
+  static_assert(RR == 4 || RR == 2 || ((E == E_RESIDUAL || E == E_STORE) && RR == 1), "rows per unit");
+  constexpr int R = RR;          // shadows the family's constant inside this kernel
+  constexpr int NP = RR / 2;     // rotate-half / gate-up pairs per unit
   constexpr int B = 1, Q = 0;
   static_assert(KS == 1 || KS == 2 || KS == 4, "KS waves per unit");
   static_assert(E != E_LOGITS || KS == 1, "logits epilogue runs one wave per unit");
@@ -670,7 +707,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, EVGPT_ROW1_OCC) void gemv_row1_ker
   if constexpr (STAGE) {
     const int u = blockIdx.x * UPB + ub_slot;
     int row[R];
-    unit_rows<E>(p, u < n_units ? u : n_units - 1, row);
+    unit_rows_n<E, RR>(p, u < n_units ? u : n_units - 1, row);
 #pragma unroll
     for (int i = 0; i < PRE; ++i) {
       const int c = c_begin + lane + 64 * i;
@@ -782,7 +819,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, EVGPT_ROW1_OCC) void gemv_row1_ker
     const int u = ub * UPB + ub_slot;
     const bool unit_ok = u < n_units;
     int row[R];
-    unit_rows<E>(p, unit_ok ? u : n_units - 1, row);
+    unit_rows_n<E, RR>(p, unit_ok ? u : n_units - 1, row);
     const unsigned char* wp[R];
     const float* sp[R];
 #pragma unroll
@@ -807,7 +844,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, EVGPT_ROW1_OCC) void gemv_row1_ker
       }
     }
 
-    float cs_in[2][B], sn_in[2][B];
+    float cs_in[NP > 0 ? NP : 1][B], sn_in[NP > 0 ? NP : 1][B];
     if constexpr (E == E_QKV_ROPE) {
       if (lane == 0 && ks == 0 && row[0] < (p.n_q_heads + p.n_kv_heads) * p.head_dim) {
         const int hh = p.head_dim >> 1, j = row[0] % p.head_dim;
@@ -815,7 +852,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, EVGPT_ROW1_OCC) void gemv_row1_ker
         for (int b = 0; b < B; ++b) {
           const int pc = pos_in[b] < 0 ? 0 : (pos_in[b] >= p.l_max ? p.l_max - 1 : pos_in[b]);
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
+          for (int i = 0; i < NP; ++i) {
             cs_in[i][b] = p.cos_tab[static_cast<size_t>(pc) * hh + j + i];
             sn_in[i][b] = p.sin_tab[static_cast<size_t>(pc) * hh + j + i];
           }
@@ -953,10 +990,10 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, EVGPT_ROW1_OCC) void gemv_row1_ker
         } else if constexpr (E == E_SWIGLU) {
           const int half = p.N >> 1;
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
+          for (int i = 0; i < NP; ++i) {
             if (row[i] < half) {
               const float g = bf16_to_f32(f32_to_bf16(acc[i][b]));
-              const float up = bf16_to_f32(f32_to_bf16(acc[2 + i][b]));
+              const float up = bf16_to_f32(f32_to_bf16(acc[NP + i][b]));
               p.y[static_cast<size_t>(b) * half + row[i]] = f32_to_bf16(silu_f(g) * up);
             }
           }
@@ -982,10 +1019,10 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, EVGPT_ROW1_OCC) void gemv_row1_ker
               dst = p.k_cache + ((static_cast<size_t>(slot) * p.n_kv_heads + h) * p.l_max + pos) * hd;
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NP; ++i) {
               const float c = cs_in[i][b], s = sn_in[i][b];
               const float x1 = bf16_to_f32(f32_to_bf16(acc[i][b]));
-              const float x2 = bf16_to_f32(f32_to_bf16(acc[2 + i][b]));
+              const float x2 = bf16_to_f32(f32_to_bf16(acc[NP + i][b]));
               dst[j + i] = f32_to_bf16(x1 * c - x2 * s);
               dst[j + i + hh] = f32_to_bf16(x2 * c + x1 * s);
             }
@@ -1089,8 +1126,34 @@ static void launch_bk(const GemvParams& p, int B, hipStream_t st) {
   dim3 g(Q && full > cap4 ? cap4 : full), b(GEMV_WAVES * 64);
   switch (B) {
     case 1:
-      if constexpr (Q == 0) hipLaunchKernelGGL((gemv_row1_kernel<P, E, KS>), g, b, smem, st, p);
-      else hipLaunchKernelGGL((gemv_kernel<1, P, E, KS, Q>), g, b, smem, st, p);
+      if constexpr (Q == 0) {
+        if constexpr (KS == 4 && E != E_LOGITS) {
+          // Rows per unit of the single-stream step (one unit per block at four waves per unit).  7B decode step,
+          // alternating on one box: residual projections (o_proj, down_proj: no prologue) 4 / 2 / 1 rows per unit
+          // 2.630 / 2.601 / 2.577 ms per token; the projections with the fused norm (qkv, gate/up) at one
+          // rotate-half or gate / up pair per unit instead of two 2.60 -> 2.74: every block stages and normalises
+          // x, and twice the blocks pay that twice.  EVGPT_ROW1_RR / EVGPT_ROW1_RR_PAIR override for tuning runs
+          // (residual: 1, 2, 4; rope / SwiGLU epilogues: 2, 4).
+          static const int rr_res = [] { const char* e = getenv("EVGPT_ROW1_RR"); return e ? atoi(e) : 1; }();
+          static const int rr_pair = [] { const char* e = getenv("EVGPT_ROW1_RR_PAIR"); return e ? atoi(e) : 4; }();
+          constexpr bool plain = E == E_RESIDUAL || E == E_STORE;
+          const int rr = plain ? rr_res : rr_pair;
+          const bool fits = p.N % 4 == 0 && (E != E_QKV_ROPE || p.head_dim % 4 == 0);
+          if (fits && rr == 2) {
+            hipLaunchKernelGGL((gemv_row1_kernel<P, E, KS, 2>), dim3((p.N + 1) / 2), b, smem, st, p);
+            break;
+          }
+          if constexpr (plain) {
+            if (fits && rr == 1) {
+              hipLaunchKernelGGL((gemv_row1_kernel<P, E, KS, 1>), dim3(p.N), b, smem, st, p);
+              break;
+            }
+          }
+        }
+        hipLaunchKernelGGL((gemv_row1_kernel<P, E, KS>), g, b, smem, st, p);
+      } else {
+        hipLaunchKernelGGL((gemv_kernel<1, P, E, KS, Q>), g, b, smem, st, p);
+      }
       break;
     case 2: hipLaunchKernelGGL((gemv_kernel<2, P, E, KS, Q>), g, b, smem, st, p); break;
     case 3: hipLaunchKernelGGL((gemv_kernel<3, P, E, KS, Q>), g, b, smem, st, p); break;
