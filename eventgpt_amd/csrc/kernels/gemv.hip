@@ -1127,7 +1127,7 @@ static void launch_bk(const GemvParams& p, int B, hipStream_t st) {
   switch (B) {
     case 1:
       if constexpr (Q == 0) {
-        if constexpr (KS == 4 && E != E_LOGITS) {
+        if constexpr (KS == 4 && E != E_LOGITS) {      // measured at four waves per unit only
           // Rows per unit of the single-stream step (one unit per block at four waves per unit).  7B decode step,
           // alternating on one box: residual projections (o_proj, down_proj: no prologue) 4 / 2 / 1 rows per unit
           // 2.630 / 2.601 / 2.577 ms per token; the projections with the fused norm (qkv, gate/up) at one
@@ -1137,15 +1137,16 @@ static void launch_bk(const GemvParams& p, int B, hipStream_t st) {
           static const int rr_res = [] { const char* e = getenv("EVGPT_ROW1_RR"); return e ? atoi(e) : 1; }();
           static const int rr_pair = [] { const char* e = getenv("EVGPT_ROW1_RR_PAIR"); return e ? atoi(e) : 4; }();
           constexpr bool plain = E == E_RESIDUAL || E == E_STORE;
+          constexpr int upb = GEMV_WAVES / KS;          // units per block
           const int rr = plain ? rr_res : rr_pair;
           const bool fits = p.N % 4 == 0 && (E != E_QKV_ROPE || p.head_dim % 4 == 0);
           if (fits && rr == 2) {
-            hipLaunchKernelGGL((gemv_row1_kernel<P, E, KS, 2>), dim3((p.N + 1) / 2), b, smem, st, p);
+            hipLaunchKernelGGL((gemv_row1_kernel<P, E, KS, 2>), dim3(((p.N + 1) / 2 + upb - 1) / upb), b, smem, st, p);
             break;
           }
           if constexpr (plain) {
             if (fits && rr == 1) {
-              hipLaunchKernelGGL((gemv_row1_kernel<P, E, KS, 1>), dim3(p.N), b, smem, st, p);
+              hipLaunchKernelGGL((gemv_row1_kernel<P, E, KS, 1>), dim3((p.N + upb - 1) / upb), b, smem, st, p);
               break;
             }
           }
