@@ -34,6 +34,7 @@ from __future__ import annotations
 import contextlib
 import dataclasses
 import functools
+import gc
 import math
 from typing import List, Optional
 
@@ -71,6 +72,21 @@ def capture_tensor_mode():
     them outside inference mode raises and leaves the generator stuck in its capturing state."""
     with torch.inference_mode(False), torch.no_grad():
         yield
+
+
+@contextlib.contextmanager
+def no_gc_during_capture():
+    """Keep Python's cyclic garbage collector from running inside a stream capture.  A collection that
+    happens to free an older engine's ``CUDAGraph`` (or anything else whose destructor calls into the HIP
+    runtime) while this thread is capturing makes that call fail, and a failure inside a destructor ends the
+    process.  ``torch.cuda.graph`` collects once before the capture begins; this covers the capture itself."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def persistent_state(method):
@@ -580,7 +596,8 @@ class GenerationEngine:
             g = torch.cuda.CUDAGraph()
             # thread-local capture mode: another host thread driving a second engine on
             # its own stream must not invalidate this capture
-            with capture_tensor_mode(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with capture_tensor_mode(), no_gc_during_capture(), \
+                    torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
         finally:
             for t, s in zip(state, saved):

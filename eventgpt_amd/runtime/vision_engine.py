@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from ..ops.hip import ACT_CODES
-from .engine import capture_tensor_mode, persistent_state
+from .engine import capture_tensor_mode, no_gc_during_capture, persistent_state
 
 
 class VisionEngine:
@@ -167,7 +167,7 @@ class VisionEngine:
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with no_gc_during_capture(), torch.cuda.graph(g):
                     static_out = self._forward(static_in, pool, n_temporal, tower_only)
             entry = (g, static_in, static_out)
             self._graphs[key] = entry

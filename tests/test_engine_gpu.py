@@ -563,3 +563,23 @@ def test_vision_engine_fused_norms_equal_separate_kernels(dev):
     cos = torch.nn.functional.cosine_similarity(a.float().flatten(1), b.float().flatten(1), dim=1)
     assert float(cos.min()) > 0.9995 and (a.float() - b.float()).abs().max().item() < 0.04 * float(b.float().abs().max())
     assert torch.equal(fused.encode(frames, pool=False), a)          # graph replay
+
+
+def test_no_garbage_collection_inside_a_capture(model, dev):
+    """Python's cyclic collector is off while a stream capture is open (a collection there can destroy an older
+    graph, whose destructor calls into the runtime that is capturing) and back on afterwards."""
+    import gc
+    eng = model.engine(max_len=256, max_new_tokens=16)
+    seen = []
+
+    def body():
+        seen.append(gc.isenabled())
+        eng._step_greedy()
+
+    assert gc.isenabled()
+    eng.reset()
+    eng.prefill((torch.randn(20, 512, device=dev) * 0.5).to(torch.bfloat16))
+    g = eng._capture(body)
+    assert seen == [True, False] and gc.isenabled()      # warm-up outside the capture, then the capture
+    g.replay()
+    torch.cuda.synchronize()
