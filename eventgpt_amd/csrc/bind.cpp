@@ -1114,6 +1114,7 @@ std::tuple<Tensor, Tensor> linear_argmax_partials(const Tensor& x, const Tensor&
 
 void gemm_force_config(int64_t cfg) { evgpt::gemm_force_config((int)cfg); }
 void gemm_enable_256(bool on) { evgpt::gemm_enable_256(on); }
+void gemm_persist_256(bool on) { evgpt::gemm_persist_256(on); }
 void attn_force_groups(int64_t g) { evgpt::attn_force_groups((int)g); }
 void gemm_enable_tail_splitk(bool on) { evgpt::gemm_enable_tail_splitk(on); }
 void attn_enable_wide(int64_t mode) { evgpt::attn_enable_wide((int)mode); }
@@ -1401,6 +1402,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("clip_preprocess(Tensor img, Tensor hstart, Tensor hcount, Tensor hweight, Tensor vstart, Tensor vcount, Tensor vweight, int S, int resize_h, int resize_w, int top, int left, float[] mean, float[] stdv) -> Tensor", &clip_preprocess);
   m.def("gemm_force_config(int cfg) -> ()", &gemm_force_config);
   m.def("gemm_enable_256(bool on) -> ()", &gemm_enable_256);
+  m.def("gemm_persist_256(bool on) -> ()", &gemm_persist_256);
   m.def("attn_force_groups(int groups) -> ()", &attn_force_groups);
   m.def("gemm_enable_tail_splitk(bool on) -> ()", &gemm_enable_tail_splitk);
   m.def("attn_enable_wide(int mode) -> ()", &attn_enable_wide);

@@ -555,52 +555,63 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   const int wr = wid >> 2, wc = wid & 3;
   const int bn_out = p.glu_half ? BN / 2 : BN;      // gated mode: W-sub0 holds gate rows, W-sub1 the up rows
   const int tiles_n = (p.N + bn_out - 1) / bn_out, tiles_m = (p.M + BM - 1) / BM;
-  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n * p.splitk);
-  const int tile = bid / p.splitk, ksplit = bid % p.splitk;
-  const int k_begin = ksplit * p.k_per_split;
-  const int k_len = min(p.k_per_split, p.K - k_begin);
-  const int tm = tile % tiles_m, tn = tile / tiles_m;
-  const int m0 = tm * BM, n0 = tn * bn_out;
-  const int nk = k_len / BK;
+  const int total = tiles_m * tiles_n * p.splitk;
 
-  // ---- staging: image = 16 wave-instructions of 1 KB, two per wave.  Per-lane source offsets
-  // of sub 0 are computed once; sub 1 and the K-tile move the (scalar) descriptor base.
-  int voff_a[2], voff_w[2];
+  // The grid is at most one workgroup per CU and a workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x,
+  // ... (gridDim.x is a multiple of 8 or the whole tile count, so a workgroup stays on its XCD's range of
+  // xcd_remap): when a tile's K loop has ended the LDS is free, so the first K-tile of the NEXT tile is staged
+  // before the epilogue and lands while the epilogue's stores drain.
+  struct Tile {
+    int m0, n0, tn, ksplit, k_begin, nk;
+    int voff_a[2], voff_w[2];      // per-lane source offsets of sub 0; sub 1 and the K-tile move the descriptor base
+  };
+  auto locate = [&](int t, Tile& c) {
+    const int bid = xcd_remap(t, total);
+    const int tile = bid / p.splitk;
+    c.ksplit = bid % p.splitk;
+    c.k_begin = c.ksplit * p.k_per_split;
+    c.nk = min(p.k_per_split, p.K - c.k_begin) / BK;
+    const int tm = tile % tiles_m;
+    c.tn = tile / tiles_m;
+    c.m0 = tm * BM;
+    c.n0 = c.tn * bn_out;
+    // ---- staging: image = 16 wave-instructions of 1 KB, two per wave (one for a 64-row A image)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int rg = wid * 2 + i;
-    if constexpr (AT) {      // image [64 k][128 columns]: columns = two runs of 64 (wave rows 0 / 1)
-      const int lin = rg * 64 + lane;
-      const int row = lin >> 4, cl = (lin & 15) ^ swz_t<128>(row);
-      voff_a[i] = (row * p.lda + m0 + (cl >> 3) * 128 + (cl & 7) * 8) * 2;
-    } else {                 // image [BM / 2 rows][64 k]: rows = two runs of QR (wave rows 0 / 1)
-      const int lr = (wid * LA + (i < LA ? i : 0)) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((lr >> 1) & 7);
-      voff_a[i] = ((m0 + (lr / QR) * (BM / 2) + (lr % QR)) * p.lda + c * 8) * 2;
+    for (int i = 0; i < 2; ++i) {
+      const int rg = wid * 2 + i;
+      if constexpr (AT) {      // image [64 k][128 columns]: columns = two runs of 64 (wave rows 0 / 1)
+        const int lin = rg * 64 + lane;
+        const int row = lin >> 4, cl = (lin & 15) ^ swz_t<128>(row);
+        c.voff_a[i] = (row * p.lda + c.m0 + (cl >> 3) * 128 + (cl & 7) * 8) * 2;
+      } else {                 // image [BM / 2 rows][64 k]: rows = two runs of QR (wave rows 0 / 1)
+        const int lr = (wid * LA + (i < LA ? i : 0)) * 8 + (lane >> 3);
+        const int cc = (lane & 7) ^ ((lr >> 1) & 7);
+        c.voff_a[i] = ((c.m0 + (lr / QR) * (BM / 2) + (lr % QR)) * p.lda + cc * 8) * 2;
+      }
+      if constexpr (BT) {      // columns = four runs of 32 (wave columns 0..3)
+        const int lin = rg * 64 + lane;
+        const int row = lin >> 4, cl = (lin & 15) ^ swz_t<128>(row);
+        c.voff_w[i] = (row * p.ldw + c.n0 + (cl >> 2) * 64 + (cl & 3) * 8) * 2;
+      } else {
+        const int lr = rg * 8 + (lane >> 3);
+        const int cc = (lane & 7) ^ ((lr >> 1) & 7);
+        c.voff_w[i] = ((c.n0 + (lr >> 5) * (p.glu_half ? 32 : 64) + (lr & 31)) * p.ldw + cc * 8) * 2;
+      }
     }
-    if constexpr (BT) {      // columns = four runs of 32 (wave columns 0..3)
-      const int lin = rg * 64 + lane;
-      const int row = lin >> 4, cl = (lin & 15) ^ swz_t<128>(row);
-      voff_w[i] = (row * p.ldw + n0 + (cl >> 2) * 64 + (cl & 3) * 8) * 2;
-    } else {
-      const int lr = rg * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((lr >> 1) & 7);
-      voff_w[i] = ((n0 + (lr >> 5) * (p.glu_half ? 32 : 64) + (lr & 31)) * p.ldw + c * 8) * 2;
-    }
-  }
+  };
   const long long bytes_a = 2ll * (AT ? p.ka_rows : p.M) * p.lda;
   const long long bytes_w = 2ll * (BT ? p.kw_rows : (p.glu_half ? 2 * p.glu_half : p.N)) * p.ldw;
   // which: 0 = A-sub0, 1 = A-sub1, 2 = W-sub0, 3 = W-sub1; kt may run past nk (zero fill)
-  auto stage = [&](int which, int kt) {
-    const int k0 = k_begin + kt * BK, h = which & 1;
+  auto stage_of = [&](const Tile& c, int which, int kt) {
+    const int k0 = c.k_begin + kt * BK, h = which & 1;
     if (which < 2) {
       unsigned char* dst = smem + (kt & 1) * TILE + which * A_HALF + wid * (LA * 1024);
       const long long adv = AT ? 2ll * k0 * p.lda + 2ll * h * 64 : 2ll * k0 + 2ll * h * QR * p.lda;
       const long long left = bytes_a - adv;
       const unsigned char* src = reinterpret_cast<const unsigned char*>(p.A) + adv;
       const int lim = static_cast<int>(left > 0 ? left : 0);
-      buffer_to_lds16(src, lim, dst, voff_a[0]);
-      if constexpr (LA == 2) buffer_to_lds16(src, lim, dst + 1024, voff_a[1]);
+      buffer_to_lds16(src, lim, dst, c.voff_a[0]);
+      if constexpr (LA == 2) buffer_to_lds16(src, lim, dst + 1024, c.voff_a[1]);
     } else {
       unsigned char* dst = smem + (kt & 1) * TILE + 2 * A_HALF + (which - 2) * W_HALF + wid * 2048;
       const long long adv = BT ? 2ll * k0 * p.ldw + 2ll * h * 32
@@ -608,16 +619,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
       const long long left = bytes_w - adv;
       const unsigned char* src = reinterpret_cast<const unsigned char*>(p.W) + adv;
       const int lim = static_cast<int>(left > 0 ? left : 0);
-      buffer_to_lds16(src, lim, dst, voff_w[0]);
-      buffer_to_lds16(src, lim, dst + 1024, voff_w[1]);
+      buffer_to_lds16(src, lim, dst, c.voff_w[0]);
+      buffer_to_lds16(src, lim, dst + 1024, c.voff_w[1]);
     }
   };
+  Tile cur;
+  int t = blockIdx.x;
+  locate(t, cur);
+  auto stage = [&](int which, int kt) { stage_of(cur, which, kt); };
 
   f32x4_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fq = lane >> 4;
   const int fsw = (frow >> 1) & 7;
@@ -683,13 +694,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   // reads of A issued after the reads of W in phase 1 (K-contiguous A: one ds_read_b128 per fragment)
   constexpr int A_READS = AT ? 0 : IS * 2;
 
-  // ---- prologue: tile 0 whole, then the three images of tile 1 the steady state keeps in flight
-  stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
-  stage(2, 1); stage(0, 1); stage(3, 1);
-  wait_vm<4 + LA>();      // the three youngest images (W, A, W) stay in flight
-  fence();
-  if (wr == 1) fence();
-
   auto tile_body = [&](auto buf_c, int kt) {
     constexpr int buf = decltype(buf_c)::value;
     // phase 1: W-sub0 is re-staged in phase 2, so its reads (issued first) are back before the barrier
@@ -719,18 +723,44 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     mma(1, 0);
     fence();
   };
-  for (int kt = 0; kt < nk; kt += 2) {
-    tile_body(std::integral_constant<int, 0>{}, kt);
-    if (kt + 1 < nk) tile_body(std::integral_constant<int, 1>{}, kt + 1);
-  }
-  if (wr == 0) fence();
-  wait_vm<0>();   // zero fills past K must have landed before the workgroup's LDS is handed on
 
-  gemm_epilogue<TM, TN, BM / 2, 64, 4>(p, acc, m0, n0, wr, wc, tn, tiles_n, ksplit, lane);
+  // ---- first tile: K-tile 0 whole
+  stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+  for (;;) {
+    // the three images of K-tile 1 the steady state keeps in flight.  The wait below counts this wave's
+    // outstanding vector-memory operations; loads complete in issue order among themselves, so once at most
+    // these three images' loads are outstanding the four images of K-tile 0 have landed, whatever the
+    // previous tile's epilogue stores (issued between the two groups) are doing.
+    stage(2, 1); stage(0, 1); stage(3, 1);
+    wait_vm<4 + LA>();
+    fence();
+    if (wr == 1) fence();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < cur.nk; kt += 2) {
+      tile_body(std::integral_constant<int, 0>{}, kt);
+      if (kt + 1 < cur.nk) tile_body(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    if (wr == 0) fence();   // both wave rows are past their last LDS read
+    wait_vm<0>();           // zero fills past K have landed: the LDS can be staged again (or handed on)
+    const int m0 = cur.m0, n0 = cur.n0, tn = cur.tn, ksplit = cur.ksplit;
+    t += gridDim.x;
+    const bool more = t < total;
+    if (more) {
+      locate(t, cur);
+      stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+    }
+    gemm_epilogue<TM, TN, BM / 2, 64, 4>(p, acc, m0, n0, wr, wc, tn, tiles_n, ksplit, lane);
+    if (!more) break;
+  }
 }
 
 static bool g_use_256 = true;
 void gemm_enable_256(bool on) { g_use_256 = on; }
+static bool g_persist_256 = true;     // false: one workgroup per tile (A/B runs)
+void gemm_persist_256(bool on) { g_persist_256 = on; }
 
 template <bool AT, bool BT, int BM = 256>
 static void launch_256(const GemmParams& p, hipStream_t st) {
@@ -743,7 +773,17 @@ static void launch_256(const GemmParams& p, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256_kernel<AT, BT, BM>), dim3(tiles), dim3(512), smem, st, p);
+  // one workgroup per CU; more tiles than CUs are walked inside the kernel (a multiple of 8 workgroups, so
+  // that a workgroup keeps its blockIdx.x % 8 -- its XCD's range of tiles -- from tile to tile)
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      n = 256;
+    n = n / 8 * 8;
+    return n < 8 ? 8 : n;
+  }();
+  const int grid = (g_persist_256 && tiles > cus) ? cus : tiles;
+  hipLaunchKernelGGL((gemm256_kernel<AT, BT, BM>), dim3(grid), dim3(512), smem, st, p);
 }
 
 // out = act(sum_s partial[s] + bias) + res, 4 columns per thread

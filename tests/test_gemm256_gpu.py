@@ -220,3 +220,46 @@ def test_forced_128_row_variant_matches_fp32(dev, M, N, K):
     finally:
         raw.gemm_force_splitk(0)
         raw.gemm_force_config(-1)
+
+
+@pytest.mark.parametrize("M,N,K", [(4643, 4608, 192), (4643, 4608, 64), (5000, 5000, 1024), (4643, 12288, 512),
+                                   (23080, 1024, 320)])
+def test_forced_256_walks_several_tiles_per_workgroup(dev, force256, M, N, K):
+    """More tiles than CUs: a workgroup runs its tiles one after the other and stages the next tile's first
+    K-tile under the epilogue of the current one.  Values, determinism, bias + residual, and equality with the
+    one-workgroup-per-tile launch."""
+    x, w = _rand(M, K, dev=dev), _rand(N, K, dev=dev, seed=1, scale=0.05)
+    bias, res = _rand(N, dev=dev, seed=2), _rand(M, N, dev=dev, seed=3)
+    want = x.float() @ w.float().t()
+    y = force256.linear(x, w, None, None, 0, False)
+    _check(y, want, K)
+    for rep in range(3):
+        assert torch.equal(force256.linear(x, w, None, None, 0, False), y), rep
+    yb = force256.linear(x, w, bias, res, 0, False)
+    _check(yb, (want + bias.float()).to(torch.bfloat16).float() + res.float(), K)
+    force256.gemm_persist_256(False)
+    try:
+        assert torch.equal(force256.linear(x, w, None, None, 0, False), y)
+        assert torch.equal(force256.linear(x, w, bias, res, 0, False), yb)
+    finally:
+        force256.gemm_persist_256(True)
+
+
+def test_persistent_256_with_k_split_glu_and_kstrided_operands(dev, force256):
+    from eventgpt_amd.ops import differentiable as diff
+    # K split: tile x split pairs beyond the CU count
+    x, w = _rand(2600, 2048, dev=dev), _rand(2560, 2048, dev=dev, seed=1, scale=0.05)
+    force256.gemm_force_splitk(4)
+    try:
+        _check(force256.linear(x, w, None, None, 0, False), x.float() @ w.float().t(), 2048)
+    finally:
+        force256.gemm_force_splitk(0)
+    # SwiGLU epilogue, 19 x 22 = 418 tiles
+    x, wg = _rand(4643, 512, dev=dev), _rand(2 * 2816, 512, dev=dev, seed=2, scale=0.05)
+    h = force256.linear_swiglu(x, wg)
+    g, u = (x.float() @ wg.float().t()).to(torch.bfloat16).float().chunk(2, -1)
+    _check(h, torch.nn.functional.silu(g) * u, 512)
+    # K-strided operands: dgrad and wgrad of a 5000-row batch
+    gy, w2, x2 = _rand(5000, 4608, dev=dev, scale=0.5), _rand(4608, 4352, dev=dev, seed=1, scale=0.05), _rand(5000, 4352, dev=dev, seed=2)
+    _check(diff.linear_dgrad(gy, w2), gy.float() @ w2.float(), 4608)
+    _check(diff.linear_wgrad(gy, x2), gy.float().t() @ x2.float(), 5000)
