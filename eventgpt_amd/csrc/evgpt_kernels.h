@@ -92,6 +92,7 @@ void gemm_force_config(int cfg);  // -1 = automatic; for tuning runs
 void attn_force_groups(int g);      // key-tile groups per 64-row attention block: 0 by shape (default), 1, 2
 void attn_wide4_min_rows(int rows); // fewest query rows that take the 128-row wide blocks
 void attn_enable_wide(int mode);   // 128-query-row prefill attention: 0 never, 1 by shape (default), 2 always
+void gemm_group_m(int g);          // row tiles per group of the 8-wave kernel's tile walk (0: whole columns)
 void gemm_persist_256(bool on);   // the 8-wave kernel walks several tiles per workgroup (default on)
 void gemm_enable_256(bool on);    // the 256 x 256 8-wave kernel for large GEMMs (default on)
 void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,

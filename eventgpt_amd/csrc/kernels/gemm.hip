@@ -86,6 +86,8 @@ struct GemmParams {
   const float* rope_cos; const float* rope_sin;     // [l_max][64]
   const int* rope_pos0;
   int rope_hq, rope_hkv, rope_lmax;
+  // 8-wave kernel: row tiles per group of its tile walk (0: whole columns)
+  int group_m;
 };
 
 // wait until at most `n` of this wave's direct-to-LDS loads are still in flight
@@ -571,8 +573,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     c.ksplit = bid % p.splitk;
     c.k_begin = c.ksplit * p.k_per_split;
     c.nk = min(p.k_per_split, p.K - c.k_begin) / BK;
-    const int tm = tile % tiles_m;
-    c.tn = tile / tiles_m;
+    // Consecutive tiles walk down GROUP_M row tiles, then move one column tile over, group after group: the 32
+    // workgroups of an XCD that run side by side then cover about 8 x 4 tiles and share 12 operand panels in
+    // their L2 instead of 33 (one column panel against 32 row panels when a tall output is walked column by
+    // column).
+    int tm, tnn;
+    if (p.group_m > 0 && tiles_m > p.group_m) {
+      const int per_group = p.group_m * tiles_n;
+      const int g = tile / per_group, within = tile % per_group;
+      const int first = g * p.group_m;
+      const int rows = min(p.group_m, tiles_m - first);
+      tm = first + within % rows;
+      tnn = within / rows;
+    } else {
+      tm = tile % tiles_m;
+      tnn = tile / tiles_m;
+    }
+    c.tn = tnn;
     c.m0 = tm * BM;
     c.n0 = c.tn * bn_out;
     // ---- staging: image = 16 wave-instructions of 1 KB, two per wave (one for a 64-row A image)
@@ -761,6 +778,8 @@ static bool g_use_256 = true;
 void gemm_enable_256(bool on) { g_use_256 = on; }
 static bool g_persist_256 = true;     // false: one workgroup per tile (A/B runs)
 void gemm_persist_256(bool on) { g_persist_256 = on; }
+static int g_group_m = 8;             // row tiles per group of the 8-wave kernel's tile walk (0: whole columns)
+void gemm_group_m(int g) { g_group_m = g; }
 
 template <bool AT, bool BT, int BM = 256>
 static void launch_256(const GemmParams& p, hipStream_t st) {
@@ -783,7 +802,9 @@ static void launch_256(const GemmParams& p, hipStream_t st) {
     return n < 8 ? 8 : n;
   }();
   const int grid = (g_persist_256 && tiles > cus) ? cus : tiles;
-  hipLaunchKernelGGL((gemm256_kernel<AT, BT, BM>), dim3(grid), dim3(512), smem, st, p);
+  GemmParams q = p;
+  q.group_m = g_group_m;
+  hipLaunchKernelGGL((gemm256_kernel<AT, BT, BM>), dim3(grid), dim3(512), smem, st, q);
 }
 
 // out = act(sum_s partial[s] + bias) + res, 4 columns per thread
