@@ -45,3 +45,24 @@ for M, N, K in [(23080, 3072, 1024), (23080, 1024, 1024), (23080, 4096, 1024), (
     raw.gemm_force_config(-1)
     lib = timeit(lambda: torch.matmul(x, w.t()))
     print(f"{'%dx%dx%d' % (M, N, K):24s} " + " ".join(f"{fl / t / 1e9:8.0f}" for t in row) + f" {fl / lib / 1e9:8.0f}", flush=True)
+
+
+print()
+print("automatic dispatch and the 4-wave tiles, whole columns (g0) against groups of 8 row tiles (g8):")
+print(f"{'shape':24s} {'auto g0':>8s} {'auto g8':>8s} {'128 g0':>8s} {'128 g8':>8s} {'64x128 g0':>10s} {'64x128 g8':>10s}")
+for M, N, K in [(636, 12288, 4096), (636, 22016, 4096), (836, 12288, 4096), (2885, 3072, 1024), (2885, 4096, 1024),
+                (4616, 4096, 1024), (4616, 1024, 4096), (2115, 12288, 4096), (2115, 4096, 11008), (4643, 12288, 4096),
+                (4643, 22016, 4096), (6688, 12288, 4096), (6688, 22016, 4096), (23080, 4096, 1024)]:
+    x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+    fl = 2.0 * M * N * K
+    row = []
+    for cfg in (-1, 0, 1):
+        raw.gemm_force_config(cfg)
+        for g in (0, 8):
+            raw.gemm_group_m(g)
+            row.append(timeit(lambda: raw.linear(x, w, None, None, 0, False)))
+    raw.gemm_force_config(-1)
+    raw.gemm_group_m(8)
+    print(f"{'%dx%dx%d' % (M, N, K):24s} " + " ".join(f"{fl / t / 1e9:8.0f}" for t in row[:4])
+          + " " + " ".join(f"{fl / t / 1e9:10.0f}" for t in row[4:]), flush=True)

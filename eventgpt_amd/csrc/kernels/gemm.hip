@@ -45,6 +45,8 @@ namespace evgpt {
 
 constexpr int BK = 64;
 
+static int g_group_m = 8;             // row tiles per group of the kernels' tile walk (0: whole columns)
+
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
@@ -86,7 +88,7 @@ struct GemmParams {
   const float* rope_cos; const float* rope_sin;     // [l_max][64]
   const int* rope_pos0;
   int rope_hq, rope_hkv, rope_lmax;
-  // 8-wave kernel: row tiles per group of its tile walk (0: whole columns)
+  // row tiles per group of the tile walk (0: whole columns); set by the launchers
   int group_m;
 };
 
@@ -132,6 +134,27 @@ __device__ __forceinline__ bf16x8_t frag_t(const unsigned char* tile, int cb, in
   const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)a2);
   const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// Tile index -> (row tile, column tile).  Consecutive tiles walk down a group of about `group_m` row tiles, then
+// move one column tile over, group after group (group_m <= 0 or few row tiles: whole columns).  The workgroups
+// of an XCD that run side by side then cover a near-square patch of the output and share its operand panels
+// in their L2 -- about 8 + 4 panels for 32 tiles instead of 32 + 1 when a tall output is walked column by
+// column.  The groups are balanced (19 row tiles at group_m = 8: 7, 7, 5).
+__device__ __forceinline__ void tile_walk(int tile, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+  if (group_m > 0 && tiles_m > group_m) {
+    const int ngroups = (tiles_m + group_m - 1) / group_m;
+    const int gsize = (tiles_m + ngroups - 1) / ngroups;
+    const int per_group = gsize * tiles_n;
+    const int g = tile / per_group, within = tile % per_group;
+    const int first = g * gsize;
+    const int rows = min(gsize, tiles_m - first);
+    tm = first + within % rows;
+    tn = within / rows;
+  } else {
+    tm = tile % tiles_m;
+    tn = tile / tiles_m;
+  }
 }
 
 // Epilogue shared by the GEMM kernels: lane holds C[m][n .. n+3] of each 16x16 tile (m = row
@@ -346,8 +369,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   const int tile = bid / p.splitk, ksplit = bid % p.splitk;
   const int k_begin = ksplit * p.k_per_split;
   const int k_len = min(p.k_per_split, p.K - k_begin);
-  // consecutive tiles walk down M first: they share one weight panel
-  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  // consecutive tiles walk down (a group of) M first: they share one weight panel
+  int tm, tn;
+  tile_walk(tile, tiles_m, tiles_n, p.group_m, tm, tn);
   const int m0 = tm * BM, n0 = tn * bn_out;
   const int wr = wid / WGN, wc = wid % WGN;
 
@@ -573,22 +597,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     c.ksplit = bid % p.splitk;
     c.k_begin = c.ksplit * p.k_per_split;
     c.nk = min(p.k_per_split, p.K - c.k_begin) / BK;
-    // Consecutive tiles walk down GROUP_M row tiles, then move one column tile over, group after group: the 32
-    // workgroups of an XCD that run side by side then cover about 8 x 4 tiles and share 12 operand panels in
-    // their L2 instead of 33 (one column panel against 32 row panels when a tall output is walked column by
-    // column).
     int tm, tnn;
-    if (p.group_m > 0 && tiles_m > p.group_m) {
-      const int per_group = p.group_m * tiles_n;
-      const int g = tile / per_group, within = tile % per_group;
-      const int first = g * p.group_m;
-      const int rows = min(p.group_m, tiles_m - first);
-      tm = first + within % rows;
-      tnn = within / rows;
-    } else {
-      tm = tile % tiles_m;
-      tnn = tile / tiles_m;
-    }
+    tile_walk(tile, tiles_m, tiles_n, p.group_m, tm, tnn);
     c.tn = tnn;
     c.m0 = tm * BM;
     c.n0 = c.tn * bn_out;
@@ -778,7 +788,6 @@ static bool g_use_256 = true;
 void gemm_enable_256(bool on) { g_use_256 = on; }
 static bool g_persist_256 = true;     // false: one workgroup per tile (A/B runs)
 void gemm_persist_256(bool on) { g_persist_256 = on; }
-static int g_group_m = 8;             // row tiles per group of the 8-wave kernel's tile walk (0: whole columns)
 void gemm_group_m(int g) { g_group_m = g; }
 
 template <bool AT, bool BT, int BM = 256>
@@ -850,8 +859,10 @@ static void launch_cfg(const GemmParams& p, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
     attr_set = true;
   }
+  GemmParams q = p;
+  q.group_m = g_group_m;
   hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES, AT, BT, KT, ROPE>), dim3(tiles), dim3(256), smem,
-                     st, p);
+                     st, q);
 }
 
 // Tile choice: the largest tile that still puts >= ~1.5 blocks on each of the 256
