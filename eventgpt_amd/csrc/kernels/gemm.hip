@@ -879,8 +879,14 @@ void gemm_force_config(int cfg) { g_forced_cfg = cfg; }
 // tiles (measured on MI355X, TFLOP/s, 8-wave vs best 4-wave config: 2115 x 4096 x 11008, 144 tiles,
 // 913 vs 751; 4643 x 12288 x 4096 1190 vs 930; 20352 x 4096 x 4096 1230 vs 905; but 636 rows 717 vs
 // 948 and 2885 x 1024 x 4096, 48 tiles, 282 vs 567).
-static bool use_256(int M, int N) {
+// K (0 = not known to the caller): a 256 x 256 tile's prologue and epilogue are one workgroup's alone (one per
+// CU), so over a short contraction the 4-wave 128 x 128 tile -- two workgroups per CU, each hiding the other's
+// ends -- is ahead.  With the grouped tile walk, TFLOP/s 8-wave vs 128 x 128: 23080 x 3072 x 1024 782 vs 816,
+// 11540 x 3072 x 1024 674 vs 771, 4616 x 4096 x 1024 547 vs 707, 4616 x 4096 x 2048 717 vs 882, but
+// 6688 x 4096 x 2048 980 vs 945, 23080 x 4096 x 2048 1102 vs 1003 and 4643 x 12288 x 4096 1253 vs 1070.
+static bool use_256(int M, int N, int K = 0) {
   const long long t = static_cast<long long>((M + 255) / 256) * ((N + 255) / 256);
+  if (K > 0 && !(K >= 4096 || (K >= 2048 && M >= 6144))) return false;
   // 768..1023 rows are three or four row tiles (up to a quarter of the last one empty): still ahead
   // once the tiles come near one round (836 x 12288 x 4096: 914 vs 833 TFLOP/s; K-strided W,
   // 836 x 11008 x 4096: 686 vs 582), behind for 64 tiles (836 x 4096: 338 vs 700)
@@ -905,14 +911,16 @@ static int narrow_256_splits(int M, int N, int K) {
 }
 
 // K = 0: the caller cannot split K (argmax partials, K-strided operands)
-static GemmCfg pick_cfg(int M, int N, int K = 0) {
+// k_real: the contraction length when the caller knows it (the tile choice depends on it), also where K = 0
+static GemmCfg pick_cfg(int M, int N, int K = 0, int k_real = 0) {
+  if (k_real == 0) k_real = K;
   if (g_forced_cfg >= 0) return static_cast<GemmCfg>(g_forced_cfg);
   auto tiles = [&](int bm, int bn) {
     return static_cast<long long>((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   };
   // thresholds from benchmarks/bench_gemm.py on MI355X
   if (M <= 32) return tiles(32, 128) >= 256 ? CFG_32x128 : CFG_32x64;
-  if (use_256(M, N)) return CFG_256x256;
+  if (use_256(M, N, k_real)) return CFG_256x256;
   if (K && narrow_256_splits(M, N, K) >= 2) return CFG_256x256;
   // Narrow outputs over a long contraction (a few hundred rows into 4096 columns over 11008, the
   // ViT's 4096 -> 1024 projection): the larger tile, its grid filled by splitting K (gemm_splitk)
@@ -948,7 +956,7 @@ int gemm_splitk(int M, int N, int K) {
       // s <= 3 (the fp32 slabs cost about one more pass over the output per split): 2115 x 4096 x 11008,
       // 144 tiles, s = 3: 231-262 -> 209 us; 1500 rows, 96 tiles, s = 2: 152 -> 130 us; 2885 rows, 192
       // tiles: every split count measures behind and the model agrees.
-      if (g_tail_splitk && K >= 8192 && use_256(M, N)) {
+      if (g_tail_splitk && K >= 8192 && use_256(M, N, K)) {
         const long long t = static_cast<long long>((M + 255) / 256) * ((N + 255) / 256);
         if (t < 256) {
           for (int s = 2; s <= 3; ++s) {
@@ -959,7 +967,7 @@ int gemm_splitk(int M, int N, int K) {
       }
       return 1;
     }
-    if (!use_256(M, N) && narrow_256_splits(M, N, K) >= 2) return narrow_256_splits(M, N, K);
+    if (!use_256(M, N, K) && narrow_256_splits(M, N, K) >= 2) return narrow_256_splits(M, N, K);
     const GemmCfg cfg = pick_cfg(M, N, K);
     const long long tl = cfg_tiles(cfg, M, N);
     int s = 1;   // fill the co-resident slots (2 blocks of 128x128, 3 of 64x128 per CU)
@@ -1015,7 +1023,7 @@ static bool last_round_split(int M, int N, int K, int* n1, int* tail_s) {
 
 // fp32 workspace (floats) the last-round split of launch_gemm_bf16 wants for this shape, 0 if none
 long long gemm_tail_ws_floats(int M, int N, int K) {
-  if (g_forced_cfg >= 0 || g_forced_splitk > 0 || !use_256(M, N)) return 0;
+  if (g_forced_cfg >= 0 || g_forced_splitk > 0 || !use_256(M, N, K)) return 0;
   int n1 = 0, s = 0;
   if (!last_round_split(M, N, K, &n1, &s) || s < 2) return 0;
   return static_cast<long long>(s) * M * (N - n1);
@@ -1050,7 +1058,7 @@ void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, co
     p.splitk = (K + p.k_per_split - 1) / p.k_per_split;  // drop empty trailing splits
     p.partial = splitk_ws;
   }
-  GemmCfg cfg = pick_cfg(M, N, (splitk_ws && !amax_val) ? K : 0);
+  GemmCfg cfg = pick_cfg(M, N, (splitk_ws && !amax_val) ? K : 0, amax_val ? 0 : K);
   if (p.k_cols) {
     // short last K-tile: the two instances compiled with the masked staging path (these are the
     // low-rank products and other short contractions; the tile choice matters little for them)
@@ -1136,7 +1144,7 @@ int gemm_splitk_t(int M, int N, int K) {
   if (g_forced_splitk > 0) return (K / 64) >= g_forced_splitk ? g_forced_splitk : 1;
   const long long t = static_cast<long long>((M + 127) / 128) * ((N + 127) / 128);
   if (g_forced_cfg >= 0 || M > 1024) return 1;
-  if (!use_256(M, N) && narrow_256_splits(M, N, K) >= 2) return narrow_256_splits(M, N, K);
+  if (!use_256(M, N, K) && narrow_256_splits(M, N, K) >= 2) return narrow_256_splits(M, N, K);
   if (t <= 32 && K >= 2048) {   // narrow output, long contraction (input gradient of a low-rank B): as in gemm_splitk
     const long long want = 256 / t, most = K / 256;
     const int s = static_cast<int>(want < most ? want : most);
@@ -1155,7 +1163,7 @@ void launch_gemm_glu(const bf16_t* A, const bf16_t* W, bf16_t* H, int M, int I, 
                nullptr, 0, K, K};
   p.glu_half = I;
   auto tiles = [&](int bm, int bn) { return static_cast<long long>((M + bm - 1) / bm) * ((2 * I + bn - 1) / bn); };
-  if (g_forced_cfg < 0 && use_256(M, 2 * I) && g_tail_splitk && I % 128 == 0) {
+  if (g_forced_cfg < 0 && use_256(M, 2 * I, K) && g_tail_splitk && I % 128 == 0) {
     // a handful of 256 x 128 output tiles past the last full round (2115 rows x 11008: 774 = 3 x 256 + 6)
     // would cost a whole further round of the 8-wave kernel: their columns go to 64 x 64 tiles instead
     const int tiles_m = (M + 255) / 256, tiles_n = I / 128;
@@ -1174,7 +1182,7 @@ void launch_gemm_glu(const bf16_t* A, const bf16_t* W, bf16_t* H, int M, int I, 
       return;
     }
   }
-  if (g_forced_cfg == CFG_256x256 || (g_forced_cfg < 0 && use_256(M, 2 * I))) launch_256<false, false>(p, st);
+  if (g_forced_cfg == CFG_256x256 || (g_forced_cfg < 0 && use_256(M, 2 * I, K))) launch_256<false, false>(p, st);
   else if (g_forced_cfg == CFG_128x128 || (g_forced_cfg < 0 && tiles(128, 128) >= 384)) launch_cfg<128, 128, 2, 2, 2>(p, st);
   else if (g_forced_cfg == CFG_64x64) launch_cfg<64, 64, 2, 2, 4>(p, st);
   else launch_cfg<64, 128, 2, 2, 3>(p, st);
@@ -1197,9 +1205,9 @@ static void launch_t(const GemmParams& p, hipStream_t st) {
       return;
     }
   }
-  if (p.splitk > 1 && cols_ok && !use_256(p.M, p.N) && narrow_256_splits(p.M, p.N, p.K) >= 2) launch_256<AT, BT>(p, st);
+  if (p.splitk > 1 && cols_ok && !use_256(p.M, p.N, p.K) && narrow_256_splits(p.M, p.N, p.K) >= 2) launch_256<AT, BT>(p, st);
   else if (p.splitk > 1) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
-  else if ((g_forced_cfg == CFG_256x256 || (g_forced_cfg < 0 && use_256(p.M, p.N))) && cols_ok) launch_256<AT, BT>(p, st);
+  else if ((g_forced_cfg == CFG_256x256 || (g_forced_cfg < 0 && use_256(p.M, p.N, p.K))) && cols_ok) launch_256<AT, BT>(p, st);
   else if (tiles(128, 128) >= 384) launch_cfg<128, 128, 2, 2, 2, AT, BT>(p, st);
   else if (tiles(64, 128) >= 300) launch_cfg<64, 128, 2, 2, 3, AT, BT>(p, st);
   else launch_cfg<64, 64, 2, 2, 4, AT, BT>(p, st);

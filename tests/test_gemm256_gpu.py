@@ -98,10 +98,11 @@ def test_auto_dispatch_uses_256_for_large_shapes(dev):
     _check(y_old, want, 4096)
 
 
-@pytest.mark.parametrize("M,N,K", [(4643, 4096, 512), (4643, 4096 + 264, 256), (2600, 6400, 128)])
+@pytest.mark.parametrize("M,N,K", [(4643, 4608, 4096), (4643, 4096 + 264, 4096), (4643, 4096, 512), (2600, 6400, 128)])
 def test_auto_dispatch_column_split_for_partial_rounds(dev, M, N, K):
-    """Tile counts just over whole rounds of CUs (304 = 256 + 48) run as two launches over disjoint
-    column ranges; every epilogue operand is offset with them."""
+    """Tile counts just over whole rounds of CUs (342 = 256 + 86, 323 = 256 + 67) run as two launches over
+    disjoint column ranges -- the tail on the 4-wave kernel or K-split on the 8-wave one; every epilogue operand is
+    offset with them.  (Contractions under 2048 take the 4-wave tiles throughout.)"""
     from eventgpt_amd.ops import hip
     x, w = _rand(M, K, dev=dev), _rand(N, K, dev=dev, seed=1, scale=0.05)
     bias, res = _rand(N, dev=dev, seed=2), _rand(M, N, dev=dev, seed=3)
