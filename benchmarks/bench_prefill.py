@@ -14,6 +14,8 @@ import os  # noqa: E402
 from eventgpt_amd.ops import hip  # noqa: E402
 
 lens = [int(a) for a in sys.argv[1:]] or [636, 2115, 4643]
+if os.environ.get("EVGPT_GROUP_M"):        # row tiles per group of the GEMM tile walk (0: whole columns)
+    hip.raw.gemm_group_m(int(os.environ["EVGPT_GROUP_M"]))
 if os.environ.get("EVGPT_GEMM_SPLITK"):    # 1: never split K in GEMMs of more than 32 rows
     hip.raw.gemm_force_splitk(int(os.environ["EVGPT_GEMM_SPLITK"]))
 if os.environ.get("EVGPT_ATTN_WIDE"):      # 0: 64-row attention blocks only, 2: 128-row blocks for every shape

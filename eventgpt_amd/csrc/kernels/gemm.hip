@@ -140,9 +140,13 @@ __device__ __forceinline__ bf16x8_t frag_t(const unsigned char* tile, int cb, in
 // move one column tile over, group after group (group_m <= 0 or few row tiles: whole columns).  The workgroups
 // of an XCD that run side by side then cover a near-square patch of the output and share its operand panels
 // in their L2 -- about 8 + 4 panels for 32 tiles instead of 32 + 1 when a tall output is walked column by
-// column.  The groups are balanced (19 row tiles at group_m = 8: 7, 7, 5).
+// column.  The groups are balanced (27 row tiles at group_m = 8: 7, 7, 7, 6).  Only from 3 group_m row tiles on:
+// every group streams the whole weight matrix again, which a tall, compute-bound product takes from the
+// die-level cache, while a few hundred rows are bound by exactly that stream (636-token prefill with groups of
+// five 64-row tiles: 11.55 -> 11.89 ms; 8192^3 on the 8-wave kernel 1182 -> 1441 TFLOP/s, 4643 x 12288 x 4096 on
+// 128 x 128 tiles 929 -> 1070, 19 row tiles of 256: no change either way).
 __device__ __forceinline__ void tile_walk(int tile, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
-  if (group_m > 0 && tiles_m > group_m) {
+  if (group_m > 0 && tiles_m >= 3 * group_m) {
     const int ngroups = (tiles_m + group_m - 1) / group_m;
     const int gsize = (tiles_m + ngroups - 1) / ngroups;
     const int per_group = gsize * tiles_n;
