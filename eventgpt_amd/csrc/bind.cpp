@@ -1116,6 +1116,7 @@ void gemm_force_config(int64_t cfg) { evgpt::gemm_force_config((int)cfg); }
 void gemm_enable_256(bool on) { evgpt::gemm_enable_256(on); }
 void gemm_persist_256(bool on) { evgpt::gemm_persist_256(on); }
 void gemm_group_m(int64_t g) { evgpt::gemm_group_m((int)g); }
+void gemm_split_major(int64_t on) { evgpt::gemm_split_major((int)on); }
 void attn_force_groups(int64_t g) { evgpt::attn_force_groups((int)g); }
 void gemm_enable_tail_splitk(bool on) { evgpt::gemm_enable_tail_splitk(on); }
 void attn_enable_wide(int64_t mode) { evgpt::attn_enable_wide((int)mode); }
@@ -1405,6 +1406,7 @@ TORCH_LIBRARY(evgpt, m) {
   m.def("gemm_enable_256(bool on) -> ()", &gemm_enable_256);
   m.def("gemm_persist_256(bool on) -> ()", &gemm_persist_256);
   m.def("gemm_group_m(int g) -> ()", &gemm_group_m);
+  m.def("gemm_split_major(int on) -> ()", &gemm_split_major);
   m.def("attn_force_groups(int groups) -> ()", &attn_force_groups);
   m.def("gemm_enable_tail_splitk(bool on) -> ()", &gemm_enable_tail_splitk);
   m.def("attn_enable_wide(int mode) -> ()", &attn_enable_wide);

@@ -93,6 +93,7 @@ void attn_force_groups(int g);      // key-tile groups per 64-row attention bloc
 void attn_wide4_min_rows(int rows); // fewest query rows that take the 128-row wide blocks
 void attn_enable_wide(int mode);   // 128-query-row prefill attention: 0 never, 1 by shape (default), 2 always
 void gemm_group_m(int g);          // row tiles per group of the 8-wave kernel's tile walk (0: whole columns)
+void gemm_split_major(int on);     // split-K workgroups of the 4-wave kernel ordered split by split
 void gemm_persist_256(bool on);   // the 8-wave kernel walks several tiles per workgroup (default on)
 void gemm_enable_256(bool on);    // the 256 x 256 8-wave kernel for large GEMMs (default on)
 void launch_gemm_bf16(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,

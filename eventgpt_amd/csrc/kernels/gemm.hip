@@ -46,6 +46,8 @@ namespace evgpt {
 constexpr int BK = 64;
 
 static int g_group_m = 8;             // row tiles per group of the kernels' tile walk (0: whole columns)
+static int g_split_major = 0;         // split-K workgroups of the 4-wave kernel ordered split by split
+void gemm_split_major(int on) { g_split_major = on; }
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
@@ -90,6 +92,8 @@ struct GemmParams {
   int rope_hq, rope_hkv, rope_lmax;
   // row tiles per group of the tile walk (0: whole columns); set by the launchers
   int group_m;
+  // 4-wave kernel with split K: workgroup index = split * tiles + tile instead of tile * splits + split
+  int split_major;
 };
 
 // wait until at most `n` of this wave's direct-to-LDS loads are still in flight
@@ -370,7 +374,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   const int bn_out = p.glu_half ? BN / 2 : BN;      // output columns per tile
   const int tiles_n = (p.N + bn_out - 1) / bn_out, tiles_m = (p.M + BM - 1) / BM;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n * p.splitk);
-  const int tile = bid / p.splitk, ksplit = bid % p.splitk;
+  // split K: tile-major (the splits of a tile are neighbours) or split-major (an XCD works inside one K range:
+  // with a few hundred rows that range of A stays in its L2 while the weights stream past)
+  const int ntile = tiles_m * tiles_n;
+  const int tile = p.split_major ? bid % ntile : bid / p.splitk;
+  const int ksplit = p.split_major ? bid / ntile : bid % p.splitk;
   const int k_begin = ksplit * p.k_per_split;
   const int k_len = min(p.k_per_split, p.K - k_begin);
   // consecutive tiles walk down (a group of) M first: they share one weight panel
@@ -865,6 +873,7 @@ static void launch_cfg(const GemmParams& p, hipStream_t st) {
   }
   GemmParams q = p;
   q.group_m = g_group_m;
+  q.split_major = (g_split_major && p.splitk > 1) ? 1 : 0;
   hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, STAGES, AT, BT, KT, ROPE>), dim3(tiles), dim3(256), smem,
                      st, q);
 }
