@@ -270,7 +270,7 @@ Tensor linear_partial(const Tensor& x, const Tensor& w, int64_t max_split) {
   TORCH_CHECK(K % 64 == 0 && N % 8 == 0, "linear_partial: K % 64 == 0 and N % 8 == 0");
   const int64_t M = x.numel() / K;
   TORCH_CHECK(M >= 1, "linear_partial: empty input");
-  int sk = evgpt::gemm_splitk((int)M, (int)N, (int)K);
+  int sk = evgpt::gemm_splitk_slabs((int)M, (int)N, (int)K);
   if (max_split > 0 && sk > max_split) sk = (int)max_split;
   Tensor ws = at::empty({sk, M, N}, x.options().dtype(at::kFloat));
   const int used = evgpt::launch_gemm_partial(bptr(x), bptr(w), ws.data_ptr<float>(), (int)M, (int)N,

@@ -105,6 +105,7 @@ void launch_gemm_glu(const bf16_t* A, const bf16_t* W, bf16_t* H, int M, int I, 
 bool launch_gemm_qkv_rope(const bf16_t* A, const bf16_t* W, int M, int K, bf16_t* q_out, bf16_t* k_cache,
                           bf16_t* v_cache, const float* cos_tab, const float* sin_tab, const int* pos0, int Hq,
                           int Hkv, int l_max, hipStream_t st);
+int gemm_splitk_slabs(int M, int N, int K);   // K splits of launch_gemm_partial (slabs summed by the caller)
 int gemm_splitk_t(int M, int N, int K);   // K splits for launch_gemm_bf16_t (1 = none)
 void launch_gemm_bf16_t(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, const bf16_t* bias,
                         const bf16_t* res, int M, int N, int K, int lda, int ldw, int ldc, int act,

@@ -910,6 +910,8 @@ static bool use_256(int M, int N, int K = 0) {
 
 static int g_forced_splitk = 0;
 static bool g_tail_splitk = true;
+// set while gemm_splitk_slabs / launch_gemm_partial plan a product whose caller sums the slabs itself
+static thread_local bool g_for_slabs = false;
 
 // 768..1024 rows into a few thousand columns over a long contraction (one ~840-token sample against
 // the 4096-wide matrices with K = 11008 / 12288 / 22016): 48..128 tiles of 256x256 are a fraction of a
@@ -942,8 +944,10 @@ static GemmCfg pick_cfg(int M, int N, int K = 0, int k_real = 0) {
   // instead of by shrinking the tile.  636 x 4096 x 11008: 128x128 with 3 splits 806 TFLOP/s,
   // 64x128 unsplit 608; 577 x 1024 x 4096: 64x128 with 3 splits 237, 32x64 unsplit 184.
   if (M <= 1024 && g_forced_splitk == 0) {
-    // (from K = 4096 on: 636 x 4096 x 4096 as 160 tiles x 3 splits 28 us for the slabs, 64 x 128 unsplit 36.7)
-    if (K >= 4096 && tiles(128, 128) >= 96 && tiles(128, 128) < 256) return CFG_128x128;
+    // (a caller that consumes the fp32 slabs itself -- g_for_slabs -- pays no reduction pass, and the same
+    // choice wins from K = 4096 on: 636 x 4096 x 4096 as 160 tiles x 3 splits 28 us, 64 x 128 unsplit 36.7;
+    // with the reduction pass it loses there, 519 vs 571 TFLOP/s)
+    if (K >= (g_for_slabs ? 4096 : 8192) && tiles(128, 128) >= 96 && tiles(128, 128) < 256) return CFG_128x128;
     if (K >= 4096 && tiles(64, 128) >= 48 && tiles(64, 128) < 128) return CFG_64x128;
   }
   if (tiles(128, 128) >= 384) return CFG_128x128;
@@ -995,7 +999,7 @@ int gemm_splitk(int M, int N, int K) {
       s = static_cast<int>(want < most ? want : most);
       return s < 1 ? 1 : (s > 16 ? 16 : s);
     }
-    if (cfg == CFG_128x128 && K >= 4096 && tl >= 96 && tl < 256) s = static_cast<int>(512 / tl);
+    if (cfg == CFG_128x128 && K >= (g_for_slabs ? 4096 : 8192) && tl >= 96 && tl < 256) s = static_cast<int>(512 / tl);
     else if (cfg == CFG_64x128 && K >= 4096 && tl >= 48 && tl < 128) s = static_cast<int>(256 / tl);
     return s < 1 ? 1 : (s > 4 ? 4 : s);
   }
@@ -1257,11 +1261,19 @@ void launch_gemm_bf16_t(const bf16_t* A, const bf16_t* W, bf16_t* C, float* Cf, 
 
 // Projection that stops at the fp32 split-K slabs partial[nslab][M][N]; returns
 // nslab (>= 1).  `partial` holds gemm_splitk(M, N, K) * M * N floats.
+// K splits of launch_gemm_partial (its caller sums the slabs, so a split costs no extra pass)
+int gemm_splitk_slabs(int M, int N, int K) {
+  g_for_slabs = true;
+  const int s = gemm_splitk(M, N, K);
+  g_for_slabs = false;
+  return s;
+}
+
 int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M, int N, int K,
                         int lda, int ldw, hipStream_t st, int max_split) {
   GemmParams p{A, W, nullptr, nullptr, nullptr, nullptr, M, N, K, lda, ldw, N, ACT_NONE, nullptr,
                nullptr, 1, K, partial, 1, K, K};
-  int splitk = gemm_splitk(M, N, K);
+  int splitk = gemm_splitk_slabs(M, N, K);
   if (max_split > 0 && splitk > max_split) splitk = max_split;
   if (splitk > 1) {
     const int ksteps = K / 64;
@@ -1269,7 +1281,10 @@ int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M,
     p.splitk = (K + p.k_per_split - 1) / p.k_per_split;
   }
   // more than 32 rows: the tile the split count was planned for (gemm_splitk picks with K in view)
-  switch (M > 32 ? pick_cfg(M, N, K) : pick_cfg(M, N)) {
+  g_for_slabs = true;
+  const GemmCfg cfg = M > 32 ? pick_cfg(M, N, K) : pick_cfg(M, N);
+  g_for_slabs = false;
+  switch (cfg) {
     case CFG_128x128: launch_cfg<128, 128, 2, 2, 2>(p, st); break;
     case CFG_64x128: launch_cfg<64, 128, 2, 2, 3>(p, st); break;
     case CFG_64x64: launch_cfg<64, 64, 2, 2, 4>(p, st); break;
