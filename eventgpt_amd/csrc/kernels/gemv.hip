@@ -1062,6 +1062,354 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, EVGPT_ROW1_OCC) void gemv_row1_ker
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// One row of x against 4-bit weights (single-stream decode).
+//
+// A 7B projection is 8-45 MB of codes: the whole launch lasts 5-15 us, so what it costs is
+// set by how early its bytes are requested and by the work per byte, not by steady-state
+// streaming.  This kernel therefore
+//   * looks codes up instead of permuting bytes: one code byte (weights j and 4+j of a word)
+//     indexes an LDS table of 256 bf16 pairs, kept once per bank so that the 32 lanes of an
+//     access group never meet in a bank (2 address instructions + 1 lookup + 1 v_dot2c per
+//     two weights, against ~7 instructions by v_perm_b32); the x image in LDS holds the
+//     matching pairs (x_j, x_4+j);
+//   * gives each wave whole rows (no cross-wave sums, no barrier after the prologue) two at
+//     a time -- a gate / up pair, a rotate-half pair or two plain rows -- in steps of
+//     W4R_NI x 2048 weights per row, and keeps two steps in flight: the loads of the first
+//     two are issued before x is staged and normalised, every later step is requested two
+//     steps before it is used.
+constexpr int W4R_WAVES = 8;                // waves per block (they share the table and the x image)
+constexpr int W4R_NI = 2;                   // 64-lane chunk-iterations per step
+constexpr int W4_TAB_BYTES = 256 * 32 * 4;  // 256 code bytes x 32 bank copies of one bf16 pair
+
+// The x image the table path multiplies against: a chunk (x0..x7) is stored as the pairs
+// (x0,x4) (x1,x5) (x2,x6) (x3,x7), the two weights one code byte carries.
+__device__ __forceinline__ u32x4_t w4_x_image(u32x4_t o) {
+  return u32x4_t{perm_b32(o[2], o[0], 0x05040100u), perm_b32(o[2], o[0], 0x07060302u),
+                 perm_b32(o[3], o[1], 0x05040100u), perm_b32(o[3], o[1], 0x07060302u)};
+}
+
+// bf16 pair of code byte i of w; tab_lane points at this lane's bank copy of entry 0
+__device__ __forceinline__ unsigned int w4_lookup(const unsigned char* tab_lane, unsigned int w, int i) {
+  return *reinterpret_cast<const unsigned int*>(tab_lane + ((w >> (8 * i)) & 0xFFu) * 128u);
+}
+
+// the row pair ("group") g of a projection
+template <int E>
+__device__ __forceinline__ void w4r_group_rows(const GemvParams& p, int g, int (&row)[2]) {
+  if constexpr (E == E_SWIGLU) {
+    row[0] = g; row[1] = (p.N >> 1) + g;            // gate row, up row
+  } else if constexpr (E == E_QKV_ROPE) {
+    const int hd = p.head_dim, hh = hd >> 1;
+    const int rot_groups = ((p.n_q_heads + p.n_kv_heads) * hd) >> 1;
+    if (g < rot_groups) {
+      const int h = g / hh, j = g - h * hh;
+      row[0] = h * hd + j; row[1] = h * hd + hh + j;  // the two halves a rotation mixes
+    } else {
+      row[0] = 2 * g; row[1] = 2 * g + 1;             // v rows
+    }
+  } else {
+    row[0] = 2 * g; row[1] = 2 * g + 1;
+  }
+}
+
+struct W4Step {
+  u32x4_t w[2][W4R_NI];
+  float sc[2][W4R_NI];
+  unsigned int aux[2];   // epilogue operands of the group: residual pair / cos, sin bits
+};
+
+template <int P, int E>
+__global__ __launch_bounds__(W4R_WAVES * 64, 2) void gemv_w4_row1_kernel(GemvParams p) {
+  static_assert(E != E_LOGITS, "the LM head is not quantised");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // LDS carve: [block-sum scratch 64 B][table 32 KB][x image K * 2 B]
+  float* red = reinterpret_cast<float*>(smem);
+  const unsigned char* tab = smem + 64;
+  u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem + 64 + W4_TAB_BYTES);
+  // the wave index as a scalar: everything derived from it (this wave's rows, its step count,
+  // the loop below) is then uniform to the compiler, which branches instead of masking lanes
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nchunk = p.K >> 3;   // 16-byte chunks of x
+  const int nwc = p.K >> 5;      // 16-byte chunks of one weight row
+  const int nblk = p.K >> 6;     // scales per weight row
+  const size_t row_bytes = static_cast<size_t>(p.K >> 1);
+  const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
+  const int nslab = (nwc + 64 * W4R_NI - 1) / (64 * W4R_NI);
+  const int n_groups = p.N >> 1;
+  const int nw = gridDim.x * W4R_WAVES;
+  const int gw = blockIdx.x * W4R_WAVES + wid;   // neighbouring waves stream neighbouring rows
+  const int n_steps = gw < n_groups ? ((n_groups - gw + nw - 1) / nw) * nslab : 0;
+
+  // Every request below is issued unconditionally, so that the count of loads in flight at
+  // each wait is the same on every path (a load under a condition makes the compiler wait
+  // for everything): a step past the wave's last one reads chunk 0 of row 0 in all lanes
+  // (one cache line) and is never used.
+  // A load from an address the compiler can see is the same in all lanes is moved to a scalar
+  // register at once, i.e. waited for where it is issued.  The epilogue operands are such loads
+  // (one position, one residual pair, one cos / sin per group), so their addresses get a zero
+  // the compiler cannot see through and the values stay in vector registers until used.
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  int pos_raw = 0;
+  if constexpr (E == E_QKV_ROPE) pos_raw = p.pos[vzero];   // the oldest load: cos / sin wait for it alone
+
+  // Row bases are uniform (scalar registers); a lane adds an unsigned 32-bit offset, which is the
+  // addressing form that needs no 64-bit vector arithmetic per load.
+  auto issue = [&](W4Step& b, int g, int slab) {
+    const bool live = g < n_groups;
+    int row[2];
+    w4r_group_rows<E>(p, live ? g : 0, row);
+    unsigned int woff[W4R_NI], soff[W4R_NI];
+#pragma unroll
+    for (int i = 0; i < W4R_NI; ++i) {
+      const int c = (slab * W4R_NI + i) * 64 + lane;
+      const int cc = live ? (c < nwc ? c : nwc - 1) : 0;   // lanes past the row re-read its last chunk and drop it
+      woff[i] = static_cast<unsigned int>(cc) * 16u;
+      soff[i] = static_cast<unsigned int>(cc >> 1) * 4u;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const unsigned char* wp = Wb + static_cast<size_t>(row[r]) * row_bytes;
+      const unsigned char* sp = reinterpret_cast<const unsigned char*>(p.absmax + static_cast<size_t>(row[r]) * nblk);
+#pragma unroll
+      for (int i = 0; i < W4R_NI; ++i) {
+        b.w[r][i] = load_stream16(wp + woff[i]);
+        b.sc[r][i] = __builtin_nontemporal_load(reinterpret_cast<const float*>(sp + soff[i]));
+      }
+    }
+  };
+  // epilogue operands of group g, requested with the weights (a load inside the epilogue
+  // would have to wait for every weight request before it)
+  auto issue_aux = [&](W4Step& b, int g) {
+    const int gg = g < n_groups ? g : 0;
+    b.aux[0] = 0; b.aux[1] = 0;
+    if constexpr (E == E_RESIDUAL) {
+      b.aux[0] = *reinterpret_cast<const unsigned int*>(p.res + 2 * gg + vzero);   // rows 2g, 2g + 1
+    } else if constexpr (E == E_QKV_ROPE) {
+      const int hh = p.head_dim >> 1;
+      const int rot_groups = ((p.n_q_heads + p.n_kv_heads) * p.head_dim) >> 1;
+      const int pc = pos_raw < 0 ? 0 : (pos_raw >= p.l_max ? p.l_max - 1 : pos_raw);
+      const int j = gg < rot_groups ? gg % hh : 0;
+      b.aux[0] = __float_as_uint(p.cos_tab[static_cast<size_t>(pc) * hh + j + vzero]);
+      b.aux[1] = __float_as_uint(p.sin_tab[static_cast<size_t>(pc) * hh + j + vzero]);
+    }
+  };
+
+  // ---- the first requests: x and the norm weights (they gate the prologue), then two steps of weights
+  constexpr int XC = 3;   // x chunks per thread: K <= 3 * 512 * 8
+  u32x4_t xr[XC], nwt[XC];
+#pragma unroll
+  for (int i = 0; i < XC; ++i) {
+    const int c = tid + i * W4R_WAVES * 64;
+    const int cc = c < nchunk ? c : 0;
+    xr[i] = load16(p.x + cc * 8);
+    if constexpr (P == P_RMSNORM) nwt[i] = load16(p.norm_w + cc * 8);
+    else nwt[i] = u32x4_t{0, 0, 0, 0};
+  }
+  W4Step b0, b1;
+  int g0 = gw, s0 = 0;          // the step held in b0
+  int g1 = gw, s1 = 1;          // the step held in b1
+  if (s1 == nslab) { s1 = 0; g1 += nw; }
+  // fences: the compiler may not interleave the requests of two steps (the waits count on their order)
+  __builtin_amdgcn_sched_barrier(0);
+  issue(b0, g0, s0);
+  issue_aux(b0, g0);     // same order as in the loop: the waits are sized for the shorter of the two
+  __builtin_amdgcn_sched_barrier(0);
+  issue(b1, g1, s1);
+  issue_aux(b1, g1);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- table: entry t = (value[t & 15], value[t >> 4]), 32 copies 4 bytes apart
+  if (tid < 256) {
+    unsigned int e[4];
+    w4_expand8(static_cast<unsigned int>(tid), p.code, e);   // weight 0 = code t & 15, weight 4 = code t >> 4
+    const unsigned int v = (e[0] & 0xFFFFu) | (e[2] << 16);
+    u32x4_t* dst = reinterpret_cast<u32x4_t*>(smem + 64 + tid * 128);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = u32x4_t{v, v, v, v};
+  }
+
+  // ---- x image (fused RMSNorm in HF order: round x * rstd to bf16, then multiply by the bf16 weight)
+  if constexpr (P == P_RMSNORM) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < XC; ++i) {
+      if (tid + i * W4R_WAVES * 64 < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = bf16lo(xr[i][j]), hi = bf16hi(xr[i][j]);
+          ss += lo * lo + hi * hi;
+        }
+      }
+    }
+    ss = block_sum(ss, red);
+    const float rstd = rsqrtf(ss / static_cast<float>(p.K) + p.eps);
+#pragma unroll
+    for (int i = 0; i < XC; ++i) {
+      const int c = tid + i * W4R_WAVES * 64;
+      u32x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = bf16_to_f32(f32_to_bf16(bf16lo(xr[i][j]) * rstd)) * bf16lo(nwt[i][j]);
+        const float hi = bf16_to_f32(f32_to_bf16(bf16hi(xr[i][j]) * rstd)) * bf16hi(nwt[i][j]);
+        o[j] = pack_bf16x2(lo, hi);
+      }
+      if (c < nchunk) xs[xs_slot<1>(c)] = w4_x_image(o);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < XC; ++i) {
+      const int c = tid + i * W4R_WAVES * 64;
+      if (c < nchunk) xs[xs_slot<1>(c)] = w4_x_image(xr[i]);
+    }
+  }
+  __syncthreads();   // the last barrier: no wave waits for another below
+
+  const unsigned char* tab_lane = tab + (lane & 31) * 4;
+  float acc[2] = {0.f, 0.f};
+
+  // Where this lane's four x chunks of iteration 0 sit in the image (bytes); iteration i of slab s
+  // is (s * W4R_NI + i) * 4096 bytes on: the swizzle of xs_slot depends on the lane alone.
+  unsigned int xoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xoff[j] = static_cast<unsigned int>(xs_slot<1>(4 * lane + j)) * 16u;
+  const unsigned char* xs_bytes = reinterpret_cast<const unsigned char*>(xs);
+
+  // No branch around the arithmetic either (a skipped wait is a wait the compiler repeats in
+  // full later): a lane past the end of the row multiplies its re-read chunk by a zero scale.
+  auto consume = [&](const W4Step& b, int slab) {
+#pragma unroll
+    for (int i = 0; i < W4R_NI; ++i) {
+      const int it = slab * W4R_NI + i;
+      const bool ok = it * 64 + lane < nwc;
+      const unsigned int xit = ok ? static_cast<unsigned int>(it) * 4096u : 0u;
+      u32x4_t xv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const u32x4_t*>(xs_bytes + xit + xoff[j]);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) s = dot2_bf16(w4_lookup(tab_lane, b.w[r][i][j], k), xv[j][k], s);
+        acc[r] = fmaf(ok ? b.sc[r][i] : 0.f, s, acc[r]);
+      }
+    }
+  };
+
+  // the row sums of group g are complete: epilogue by lane 0 (stores only)
+  auto finish = [&](const W4Step& b, int g) {
+    const float a0 = wave_sum(acc[0]), a1 = wave_sum(acc[1]);
+    acc[0] = 0.f; acc[1] = 0.f;
+    if (lane != 0) return;
+    int row[2];
+    w4r_group_rows<E>(p, g, row);
+    if constexpr (E == E_STORE) {
+      const float a[2] = {a0, a1};
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        if (p.yf) p.yf[row[r]] = a[r];
+        else p.y[row[r]] = f32_to_bf16(a[r]);
+      }
+    } else if constexpr (E == E_RESIDUAL) {
+      const float a[2] = {a0, a1};
+      const float res[2] = {bf16lo(b.aux[0]), bf16hi(b.aux[0])};
+      unsigned int out = 0;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const float sum = bf16_to_f32(f32_to_bf16(a[r])) + res[r];
+        out |= static_cast<unsigned int>(__builtin_bit_cast(unsigned short, f32_to_bf16(sum))) << (16 * r);
+      }
+      *reinterpret_cast<unsigned int*>(p.y + row[0]) = out;
+    } else if constexpr (E == E_SWIGLU) {
+      const float gate = bf16_to_f32(f32_to_bf16(a0)), up = bf16_to_f32(f32_to_bf16(a1));
+      p.y[row[0]] = f32_to_bf16(silu_f(gate) * up);
+    } else if constexpr (E == E_QKV_ROPE) {
+      const int hd = p.head_dim, hh = hd >> 1;
+      const int q_rows = p.n_q_heads * hd, k_rows = p.n_kv_heads * hd;
+      // the position is a device counter: clamp it into the cache so a sequence that ran
+      // past its capacity overwrites the last slot instead of writing outside the allocation
+      const int pos = pos_raw < 0 ? 0 : (pos_raw >= p.l_max ? p.l_max - 1 : pos_raw);
+      const bool kv_ok = !p.rows_one_seq || (pos_raw >= 0 && pos_raw < p.l_max);
+      if (row[0] < q_rows + k_rows) {
+        const int h_all = row[0] / hd, j = row[0] - h_all * hd;   // j < hh
+        bf16_t* dst;
+        if (h_all < p.n_q_heads) {
+          dst = p.q_out + h_all * hd;
+        } else {
+          if (!kv_ok) return;
+          dst = p.k_cache + (static_cast<size_t>(h_all - p.n_q_heads) * p.l_max + pos) * hd;
+        }
+        const float c = __uint_as_float(b.aux[0]), sn = __uint_as_float(b.aux[1]);
+        const float x1 = bf16_to_f32(f32_to_bf16(a0)), x2 = bf16_to_f32(f32_to_bf16(a1));
+        dst[j] = f32_to_bf16(x1 * c - x2 * sn);
+        dst[j + hh] = f32_to_bf16(x2 * c + x1 * sn);
+      } else {
+        if (!kv_ok) return;
+        const int vr = row[0] - q_rows - k_rows;
+        const int h = vr / hd, j = vr - h * hd;
+        bf16_t* dst = p.v_cache + (static_cast<size_t>(h) * p.l_max + pos) * hd;
+        dst[j] = f32_to_bf16(a0);
+        dst[j + 1] = f32_to_bf16(a1);
+      }
+    }
+  };
+
+  auto advance2 = [&](int& g, int& s) {   // two steps on
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (++s == nslab) { s = 0; g += nw; }
+  };
+
+  // Pairs of steps; an odd last step follows the loop (a break between the two halves would
+  // give the loop a second exit whose request count the waits of the first half had to assume).
+  int t = 0;
+  for (; t + 1 < n_steps; t += 2) {
+    consume(b0, s0);
+    if (s0 == nslab - 1) finish(b0, g0);
+    advance2(g0, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(b0, g0, s0);
+    issue_aux(b0, g0);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(b1, s1);
+    if (s1 == nslab - 1) finish(b1, g1);
+    advance2(g1, s1);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(b1, g1, s1);
+    issue_aux(b1, g1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (t < n_steps) {
+    consume(b0, s0);
+    if (s0 == nslab - 1) finish(b0, g0);
+  }
+}
+
+// shapes the one-row 4-bit kernel takes: row pairs, whole scale blocks, the table and the x
+// image inside the 64 KB a launch may ask for without opting in
+static bool w4_row1_ok(const GemvParams& p, int B, int E) {
+  static const bool on = [] { const char* e = getenv("EVGPT_W4_ROW1"); return !e || atoi(e) != 0; }();
+  if (!on || B != 1 || !p.absmax || E == E_LOGITS) return false;
+  if (p.bias || p.act != ACT_NONE) return false;   // no load may sit in this kernel's epilogue
+  if (p.N % 2 != 0 || p.K % 64 != 0) return false;
+  if (E == E_QKV_ROPE && p.head_dim % 2 != 0) return false;
+  return p.K <= 3 * W4R_WAVES * 64 * 8;   // the x chunks a block keeps in registers through the norm
+}
+
+template <int P, int E>
+static void launch_w4_row1(const GemvParams& p, hipStream_t st) {
+  const size_t smem = 64 + W4_TAB_BYTES + static_cast<size_t>(p.K) * 2;
+  // two blocks per CU hold their tables and x images at once; fewer blocks when there are
+  // fewer row pairs than waves
+  static const int cap = [] { const char* e = getenv("EVGPT_W4_ROW1_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
+  const int groups = p.N >> 1;
+  const int want = (groups + W4R_WAVES - 1) / W4R_WAVES;
+  hipLaunchKernelGGL((gemv_w4_row1_kernel<P, E>), dim3(want < cap ? want : cap), dim3(W4R_WAVES * 64), smem, st, p);
+}
+
 static int g_forced_ks = 0;
 void gemv_force_ks(int ks) { g_forced_ks = ks; }   // 0 = automatic; for tuning runs
 
@@ -1170,6 +1518,8 @@ template <int P, int E>
 static void launch_b(const GemvParams& p, int B, hipStream_t st) {
   if constexpr (E == E_LOGITS) {
     launch_bk<P, E, 1, 0>(p, B, st);
+  } else if (w4_row1_ok(p, B, E)) {
+    launch_w4_row1<P, E>(p, st);
   } else if (p.absmax) {
     // a 4-bit row is a quarter of the bytes, so half the waves per unit keep the per-wave
     // work (and the share of a block's prologue) comparable; measured on the 7B decode
