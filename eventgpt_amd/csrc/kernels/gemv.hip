@@ -1276,27 +1276,60 @@ __global__ __launch_bounds__(W4R_WAVES * 64, 2) void gemv_w4_row1_kernel(GemvPar
   for (int j = 0; j < 4; ++j) xoff[j] = static_cast<unsigned int>(xs_slot<1>(4 * lane + j)) * 16u;
   const unsigned char* xs_bytes = reinterpret_cast<const unsigned char*>(xs);
 
+  // One step = four batches (iteration, row) of 16 lookups and 16 v_dot2c.  The lookups of a
+  // batch are issued a batch ahead of their dot products, behind fences the scheduler may not
+  // move code across: left alone it emits eight lookups, waits for them and runs eight dependent
+  // dot products, and the LDS round trip of every such group (sixteen per step) is exposed.
   // No branch around the arithmetic either (a skipped wait is a wait the compiler repeats in
   // full later): a lane past the end of the row multiplies its re-read chunk by a zero scale.
-  auto consume = [&](const W4Step& b, int slab) {
+  auto lookups = [&](const u32x4_t& w, unsigned int (&e)[16]) {
 #pragma unroll
-    for (int i = 0; i < W4R_NI; ++i) {
-      const int it = slab * W4R_NI + i;
-      const bool ok = it * 64 + lane < nwc;
-      const unsigned int xit = ok ? static_cast<unsigned int>(it) * 4096u : 0u;
-      u32x4_t xv[4];
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const u32x4_t*>(xs_bytes + xit + xoff[j]);
+      for (int k = 0; k < 4; ++k) e[4 * j + k] = w4_lookup(tab_lane, w[j], k);
+  };
+  auto dots = [&](const unsigned int (&e)[16], const u32x4_t (&xv)[4], float scale, float& a) {
+    float s0 = 0.f, s1 = 0.f;   // two chains: a v_dot2c does not wait for the one before it
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) s = dot2_bf16(w4_lookup(tab_lane, b.w[r][i][j], k), xv[j][k], s);
-        acc[r] = fmaf(ok ? b.sc[r][i] : 0.f, s, acc[r]);
-      }
+    for (int j = 0; j < 4; ++j) {
+      s0 = dot2_bf16(e[4 * j + 0], xv[j][0], s0);
+      s1 = dot2_bf16(e[4 * j + 1], xv[j][1], s1);
+      s0 = dot2_bf16(e[4 * j + 2], xv[j][2], s0);
+      s1 = dot2_bf16(e[4 * j + 3], xv[j][3], s1);
     }
+    a = fmaf(scale, s0 + s1, a);
+  };
+  static_assert(W4R_NI == 2, "the batch schedule below is written out for two iterations per step");
+  auto consume = [&](const W4Step& b, int slab) {
+    bool ok[2];
+    unsigned int xit[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int it = slab * W4R_NI + i;
+      ok[i] = it * 64 + lane < nwc;
+      xit[i] = ok[i] ? static_cast<unsigned int>(it) * 4096u : 0u;
+    }
+    u32x4_t xv0[4], xv1[4];
+    unsigned int ea[16], eb[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xv0[j] = *reinterpret_cast<const u32x4_t*>(xs_bytes + xit[0] + xoff[j]);
+    lookups(b.w[0][0], ea);
+    __builtin_amdgcn_sched_barrier(0);
+    lookups(b.w[1][0], eb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xv1[j] = *reinterpret_cast<const u32x4_t*>(xs_bytes + xit[1] + xoff[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    dots(ea, xv0, ok[0] ? b.sc[0][0] : 0.f, acc[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    lookups(b.w[0][1], ea);
+    __builtin_amdgcn_sched_barrier(0);
+    dots(eb, xv0, ok[0] ? b.sc[1][0] : 0.f, acc[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    lookups(b.w[1][1], eb);
+    __builtin_amdgcn_sched_barrier(0);
+    dots(ea, xv1, ok[1] ? b.sc[0][1] : 0.f, acc[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    dots(eb, xv1, ok[1] ? b.sc[1][1] : 0.f, acc[1]);
   };
 
   // the row sums of group g are complete: epilogue by lane 0 (stores only)

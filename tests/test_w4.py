@@ -91,7 +91,8 @@ def test_dequant_kernel_equals_oracle(kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B", [1, 2, 3])
-@pytest.mark.parametrize("N,K", [(4096, 4096), (512, 11008), (12288, 256), (24576, 64), (260, 192)])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (512, 11008), (12288, 256), (24576, 64), (260, 192), (4096, 11008),
+                                 (6, 8192), (20002, 4160)])
 def test_gemv_residual_w4(B, N, K):
     from eventgpt_amd.ops import hip
     q = Q.quantize_weight(_rand((N, K), N + K, 0.02)).to(_dev())
@@ -106,14 +107,18 @@ def test_gemv_residual_w4(B, N, K):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [1, 3])
-def test_mlp_up_and_qkv_w4_match_bf16_kernels_on_dequantised_weights(B):
-    """The fused-epilogue variants against the bf16 kernels fed the dequantised matrix."""
+@pytest.mark.parametrize("B,geom", [(1, (512, 1408, 8, 64)), (3, (512, 1408, 8, 64)),
+                                    (1, (4096, 11008, 32, 128)),   # the 7B layer: several steps per wave
+                                    (1, (2112, 2880, 6, 96))])     # rows end inside a 64-lane iteration
+def test_mlp_up_and_qkv_w4_match_bf16_kernels_on_dequantised_weights(B, geom):
+    """The fused-epilogue variants against the bf16 kernels fed the dequantised matrix (one row: the
+    dedicated one-row kernel; more rows: the generic one)."""
     from eventgpt_amd import ops
     from eventgpt_amd.ops import hip
     raw = hip.raw
     dev = _dev()
-    H, I, Hq, D, L = 512, 1408, 8, 64, 64
+    H, I, Hq, D = geom
+    L = 64
     x = _rand((B, H), 9).to(dev, torch.bfloat16)
     nw = (1 + 0.1 * _rand((H,), 10)).to(dev, torch.bfloat16)
     qgu = Q.quantize_weight(_rand((2 * I, H), 11, 0.03)).to(dev)
