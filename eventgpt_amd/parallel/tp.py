@@ -232,9 +232,11 @@ class TensorParallelEngine(GenerationEngine):
                           and dist.get_backend(group) == "gloo")
         if self._gloo:
             kw["use_graph"] = False     # gloo collectives go through host copies: nothing to capture
-        if kw.get("weight_format", "bf16") != "bf16":
-            raise NotImplementedError("the batched / tensor-parallel engine runs bf16 weights; 4-bit weights "
-                                      "are a GenerationEngine (single stream, <= 3 rows) format")
+        if kw.get("weight_format", "bf16") != "bf16" and group is not None and dist.is_initialized() \
+                and dist.get_world_size(group) > 1:
+            raise NotImplementedError("4-bit weights are not sharded: a tensor-parallel engine of several ranks "
+                                      "runs bf16 weights (one rank: up to 3 sequences stream the codes, more "
+                                      "multiply by the dequantised matrices)")
         super().__init__(model, max_len=max_len, max_batch=max_batch, **kw)
         dev = self.device
         self.oneshot = None
@@ -444,16 +446,16 @@ class TensorParallelEngine(GenerationEngine):
             kc, vc = l.k_cache[batch:batch + 1], l.v_cache[batch:batch + 1]
             xn = raw.rmsnorm(x, l.norm1, self.eps).view(S, self.H)
             # this rank's heads: RoPE + cache append in the projection's epilogue where the tile allows it
-            if not (rope_gemm and raw.linear_qkv_rope(xn, l.w_qkv, q, kc, vc, self.cos, self.sin, pos0,
+            if not (rope_gemm and raw.linear_qkv_rope(xn, self._w(l, "w_qkv"), q, kc, vc, self.cos, self.sin, pos0,
                                                       self.Hq, self.Hkv)):
                 rope_gemm = False
-                qkv = raw.linear(xn, l.w_qkv, None, None, 0, False).view(1, S, -1)
+                qkv = raw.linear(xn, self._w(l, "w_qkv"), None, None, 0, False).view(1, S, -1)
                 raw.prefill_rope_kv(qkv, q, kc, vc, self.cos, self.sin, pos0, self.Hq, self.Hkv, self.D)
             raw.attention_cache(q, kc, vc, o, kv_len, self.scale)
-            x = self._reduce(raw.linear(o.view(1, S, self.Hq * self.D), l.w_o, None,
+            x = self._reduce(raw.linear(o.view(1, S, self.Hq * self.D), self._w(l, "w_o"), None,
                                         x if lead else None, 0, False))
-            h = self._mlp_up(raw.rmsnorm(x, l.norm2, self.eps), l.w_gate_up)
-            x = self._reduce(raw.linear(h, l.w_down, None, x if lead else None, 0, False))
+            h = self._mlp_up(raw.rmsnorm(x, l.norm2, self.eps), self._w(l, "w_gate_up"))
+            x = self._reduce(raw.linear(h, self._w(l, "w_down"), None, x if lead else None, 0, False))
         return x
 
     #: most rows one packed prefill pass carries (bounds the [rows, 3H] / [rows, 2I] temporaries)
@@ -477,7 +479,7 @@ class TensorParallelEngine(GenerationEngine):
         o = torch.empty_like(q)
         lead = self.tp_rank == 0
         for l in self.layers:
-            qkv = raw.linear(raw.rmsnorm(x, l.norm1, self.eps), l.w_qkv, None, None, 0, False).view(T, -1)
+            qkv = raw.linear(raw.rmsnorm(x, l.norm1, self.eps), self._w(l, "w_qkv"), None, None, 0, False).view(T, -1)
             for i, b in enumerate(slots):
                 a, e = offs[i], offs[i + 1]
                 kc, vc = l.k_cache[b:b + 1], l.v_cache[b:b + 1]
@@ -485,9 +487,9 @@ class TensorParallelEngine(GenerationEngine):
                 raw.prefill_rope_kv(qkv[a:e].view(1, e - a, -1), qi, kc, vc, self.cos, self.sin, pos0,
                                     self.Hq, self.Hkv, self.D)
                 raw.attention_cache(qi, kc, vc, oi, lens_d[i:i + 1], self.scale)
-            x = self._reduce(raw.linear(o.view(1, T, self.Hq * self.D), l.w_o, None, x if lead else None, 0, False))
-            h = self._mlp_up(raw.rmsnorm(x, l.norm2, self.eps), l.w_gate_up)
-            x = self._reduce(raw.linear(h, l.w_down, None, x if lead else None, 0, False))
+            x = self._reduce(raw.linear(o.view(1, T, self.Hq * self.D), self._w(l, "w_o"), None, x if lead else None, 0, False))
+            h = self._mlp_up(raw.rmsnorm(x, l.norm2, self.eps), self._w(l, "w_gate_up"))
+            x = self._reduce(raw.linear(h, self._w(l, "w_down"), None, x if lead else None, 0, False))
         return [x[0, offs[i + 1] - 1] for i in range(len(slots))]
 
     def _prefill_slots(self, slots: Sequence[int], embeds_list: Sequence[torch.Tensor]) -> None:
@@ -531,26 +533,26 @@ class TensorParallelEngine(GenerationEngine):
             n = len(self.layers)
             xn = raw.rmsnorm(x, self.layers[0].norm1, self.eps)
             for i, l in enumerate(self.layers):
-                raw.reduce_rope_kv(raw.linear_partial(xn, l.w_qkv), self.q, l.k_cache, l.v_cache,
+                raw.reduce_rope_kv(raw.linear_partial(xn, self._w(l, "w_qkv")), self.q, l.k_cache, l.v_cache,
                                    self.cos, self.sin, self.pos, B, 1, self.Hq, self.Hkv, self.D)
                 raw.decode_attn(self.q, l.k_cache, l.v_cache, self.attn, self.part_o, self.part_ml,
                                 self.pos, self.nsplit, self.scale)
-                x, xn = self._reduce_residual_norm(self._row_partial(self.attn, l.w_o), x, l.norm2)
-                h = raw.reduce_swiglu(raw.linear_partial(xn, l.w_gate_up))
+                x, xn = self._reduce_residual_norm(self._row_partial(self.attn, self._w(l, "w_o")), x, l.norm2)
+                h = raw.reduce_swiglu(raw.linear_partial(xn, self._w(l, "w_gate_up")))
                 nxt = self.layers[i + 1].norm1 if i + 1 < n else None
-                x, xn = self._reduce_residual_norm(self._row_partial(h, l.w_down), x, nxt)
+                x, xn = self._reduce_residual_norm(self._row_partial(h, self._w(l, "w_down")), x, nxt)
             self.x.copy_(x)
             return
         lead = self.tp_rank == 0
         for l in self.layers:
-            qkv = raw.linear(raw.rmsnorm(x, l.norm1, self.eps), l.w_qkv, None, None, 0, False)
+            qkv = raw.linear(raw.rmsnorm(x, l.norm1, self.eps), self._w(l, "w_qkv"), None, None, 0, False)
             raw.prefill_rope_kv(qkv.view(B, 1, -1), self.q.view(B, 1, -1), l.k_cache, l.v_cache,
                                 self.cos, self.sin, self.pos, self.Hq, self.Hkv, self.D)
             raw.decode_attn(self.q, l.k_cache, l.v_cache, self.attn, self.part_o, self.part_ml,
                             self.pos, self.nsplit, self.scale)
-            x = self._reduce(raw.linear(self.attn, l.w_o, None, x if lead else None, 0, False))
-            h = self._mlp_up(raw.rmsnorm(x, l.norm2, self.eps), l.w_gate_up)
-            x = self._reduce(raw.linear(h, l.w_down, None, x if lead else None, 0, False))
+            x = self._reduce(raw.linear(self.attn, self._w(l, "w_o"), None, x if lead else None, 0, False))
+            h = self._mlp_up(raw.rmsnorm(x, l.norm2, self.eps), self._w(l, "w_gate_up"))
+            x = self._reduce(raw.linear(h, self._w(l, "w_down"), None, x if lead else None, 0, False))
         self.x.copy_(x)
 
     # ------------------------------------------------------------------ head

@@ -346,28 +346,34 @@ class GenerationEngine:
         return x.view(1, S, self.H)
 
     # the four weight-streaming launches of a layer, in either weight format
+    def _w4_rows(self, rows: int) -> bool:
+        """4-bit weights are streamed as codes for up to ``gemv_w4_max_batch`` rows; a step of more
+        sequences multiplies by the dequantised bf16 matrices (``_w``), as every multi-row pass does:
+        the same quantised model, at the bf16 kernels' speed."""
+        return self.w4 and rows <= int(self.raw.gemv_w4_max_batch())
+
     def _gemv_qkv(self, l, x, q, kc, vc, pos, one_seq: bool) -> None:
-        if self.w4:
+        if self._w4_rows(x.shape[0]):
             w = l.q4["w_qkv"]
             self.raw.decode_qkv_w4(x, l.norm1, w.packed, w.absmax, w.code, q, kc, vc, self.cos, self.sin,
                                    pos, self.eps, self.Hq, self.Hkv, self.D, one_seq)
         else:
-            self.raw.decode_qkv(x, l.norm1, l.w_qkv, q, kc, vc, self.cos, self.sin, pos, self.eps,
+            self.raw.decode_qkv(x, l.norm1, self._w(l, "w_qkv"), q, kc, vc, self.cos, self.sin, pos, self.eps,
                                 self.Hq, self.Hkv, self.D, one_seq)
 
     def _gemv_residual(self, l, name: str, xin, y) -> None:
-        if self.w4:
+        if self._w4_rows(xin.shape[0]):
             w = l.q4[name]
             self.raw.decode_gemv_residual_w4(w.packed, w.absmax, w.code, xin, y)
         else:
-            self.raw.decode_gemv_residual(getattr(l, name), xin, y)
+            self.raw.decode_gemv_residual(self._w(l, name), xin, y)
 
     def _gemv_mlp_up(self, l, x, h) -> None:
-        if self.w4:
+        if self._w4_rows(x.shape[0]):
             w = l.q4["w_gate_up"]
             self.raw.decode_mlp_up_w4(w.packed, w.absmax, w.code, x, l.norm2, self.eps, h)
         else:
-            self.raw.decode_mlp_up(l.w_gate_up, x, l.norm2, self.eps, h)
+            self.raw.decode_mlp_up(self._w(l, "w_gate_up"), x, l.norm2, self.eps, h)
 
     # Row counts up to this take the few-row path: projections stop at their fp32
     # split-K slabs and the op that follows (RoPE + cache append, residual + next
@@ -544,8 +550,9 @@ class GenerationEngine:
     # ------------------------------------------------------------ decode step
     def _layers_step(self) -> None:
         raw = self.raw
-        if self.w4 and self.B > int(raw.gemv_w4_max_batch()):
-            raise RuntimeError(f"4-bit decode steps take up to {int(raw.gemv_w4_max_batch())} sequences")
+        if self.B > int(raw.gemv_max_batch()):
+            raise RuntimeError(f"decode steps of more than {int(raw.gemv_max_batch())} sequences run on "
+                               "parallel.tp.TensorParallelEngine (also with one rank)")
         for l in self.layers:
             self._gemv_qkv(l, self.x, self.q, l.k_cache, l.v_cache, self.pos, False)
             raw.decode_attn(self.q, l.k_cache, l.v_cache, self.attn, self.part_o, self.part_ml,

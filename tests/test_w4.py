@@ -225,3 +225,34 @@ def test_engine_w4_generate_graph_equals_eager_and_verify_paths():
         eg.verify(draft)
         res = eg.sd_result.tolist()
         assert res[0] == G and res[1] == int(te[1 + G]), (G, res, te[:G + 2].tolist())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("release", [False, True])
+def test_batched_engine_w4_more_streams_than_the_4bit_gemv_takes(release):
+    """Six streams on a 4-bit batched engine (one rank): the step multiplies by the dequantised matrices with
+    the bf16 kernels, so it is the bf16 engine on the fake-quantised model, token for token -- also when the
+    bf16 copies were dropped and every matrix is expanded into scratch where it is used."""
+    from eventgpt_amd.models import EventChatConfig, EventChatModel
+    from eventgpt_amd.parallel.tp import TensorParallelEngine
+    from eventgpt_amd.ops import hip
+    cfg = EventChatConfig(vocab_size=512, hidden_size=256, intermediate_size=704, num_hidden_layers=2,
+                          num_attention_heads=4, max_position_embeddings=256)
+    B = int(hip.raw.gemv_w4_max_batch()) + 3
+    m4 = EventChatModel.from_config(cfg, torch.bfloat16, _dev(), seed=5)
+    mb = EventChatModel.from_config(cfg, torch.bfloat16, _dev(), seed=5)
+    Q.fake_quantize_model_(mb, "nf4")
+    e4 = TensorParallelEngine(m4, None, max_len=128, max_batch=B, max_new_tokens=24, weight_format="nf4",
+                              release_bf16=release)
+    eb = TensorParallelEngine(mb, None, max_len=128, max_batch=B, max_new_tokens=24)
+    embs = [_rand((9 + 2 * b, 256), 20 + b, 0.5).to(_dev(), torch.bfloat16) for b in range(B)]
+    e4.prefill_batch(embs)
+    eb.prefill_batch(embs)
+    for _ in range(10):
+        e4.decode_step(True); eb.decode_step(True)
+    torch.cuda.synchronize()
+    assert torch.equal(e4.out_tokens[:, :11], eb.out_tokens[:, :11])
+    assert torch.equal(e4.pos, eb.pos)
+    with pytest.raises(RuntimeError, match="TensorParallelEngine"):
+        from eventgpt_amd.runtime.engine import GenerationEngine
+        GenerationEngine(mb, max_len=128, max_batch=B, max_new_tokens=8, use_graph=False).decode_step(True)
