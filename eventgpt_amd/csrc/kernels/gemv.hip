@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64, EVGPT_ROW1_OCC) void gemv_row1_ker
 }
 
 // ---------------------------------------------------------------------------------------
-// One row of x against 4-bit weights (single-stream decode).
+// One to three rows of x against 4-bit weights (single-stream decode, short verifies, two or three streams).
 //
 // A 7B projection is 8-45 MB of codes: the whole launch lasts 5-15 us, so what it costs is
 // set by how early its bytes are requested and by the work per byte, not by steady-state
@@ -1113,20 +1113,25 @@ __device__ __forceinline__ void w4r_group_rows(const GemvParams& p, int g, int (
   }
 }
 
+template <int B>
 struct W4Step {
   u32x4_t w[2][W4R_NI];
   float sc[2][W4R_NI];
-  unsigned int aux[2];   // epilogue operands of the group: residual pair / cos, sin bits
+  unsigned int aux[B][2];   // epilogue operands of the group, per x row: residual pair / cos, sin bits
 };
 
-template <int P, int E>
-__global__ __launch_bounds__(W4R_WAVES * 64, 2) void gemv_w4_row1_kernel(GemvParams p) {
+// B x rows (1..3: the single-stream step, short speculative verifies, two or three streams) share every
+// lookup: a code byte is looked up once and multiplied into B sums.
+template <int P, int E, int B>
+__global__ __launch_bounds__(W4R_WAVES * 64, B == 1 ? 2 : 1) void gemv_w4_rows_kernel(GemvParams p) {
   static_assert(E != E_LOGITS, "the LM head is not quantised");
+  static_assert(B >= 1 && B <= 3, "x rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // LDS carve: [block-sum scratch 64 B][table 32 KB][x image K * 2 B]
+  // LDS carve: [block-sum scratch 64 B][table 32 KB][B x images of K * 2 B]
   float* red = reinterpret_cast<float*>(smem);
   const unsigned char* tab = smem + 64;
-  u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem + 64 + W4_TAB_BYTES);
+  unsigned char* xs_bytes = smem + 64 + W4_TAB_BYTES;
+  const unsigned int x_bytes = static_cast<unsigned int>(p.K) * 2u;   // one image
   // the wave index as a scalar: everything derived from it (this wave's rows, its step count,
   // the loop below) is then uniform to the compiler, which branches instead of masking lanes
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1147,16 +1152,21 @@ __global__ __launch_bounds__(W4R_WAVES * 64, 2) void gemv_w4_row1_kernel(GemvPar
   // (one cache line) and is never used.
   // A load from an address the compiler can see is the same in all lanes is moved to a scalar
   // register at once, i.e. waited for where it is issued.  The epilogue operands are such loads
-  // (one position, one residual pair, one cos / sin per group), so their addresses get a zero
+  // (positions, one residual pair, one cos / sin per group and x row), so their addresses get a zero
   // the compiler cannot see through and the values stay in vector registers until used.
   int vzero;
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-  int pos_raw = 0;
-  if constexpr (E == E_QKV_ROPE) pos_raw = p.pos[vzero];   // the oldest load: cos / sin wait for it alone
+  int pos_raw[B];
+#pragma unroll
+  for (int b = 0; b < B; ++b) pos_raw[b] = 0;
+  if constexpr (E == E_QKV_ROPE) {   // the oldest loads: cos / sin wait for them alone
+#pragma unroll
+    for (int b = 0; b < B; ++b) pos_raw[b] = p.rows_one_seq ? p.pos[vzero] + b : p.pos[b + vzero];
+  }
 
   // Row bases are uniform (scalar registers); a lane adds an unsigned 32-bit offset, which is the
   // addressing form that needs no 64-bit vector arithmetic per load.
-  auto issue = [&](W4Step& b, int g, int slab) {
+  auto issue = [&](W4Step<B>& st, int g, int slab) {
     const bool live = g < n_groups;
     int row[2];
     w4r_group_rows<E>(p, live ? g : 0, row);
@@ -1174,40 +1184,44 @@ __global__ __launch_bounds__(W4R_WAVES * 64, 2) void gemv_w4_row1_kernel(GemvPar
       const unsigned char* sp = reinterpret_cast<const unsigned char*>(p.absmax + static_cast<size_t>(row[r]) * nblk);
 #pragma unroll
       for (int i = 0; i < W4R_NI; ++i) {
-        b.w[r][i] = load_stream16(wp + woff[i]);
-        b.sc[r][i] = __builtin_nontemporal_load(reinterpret_cast<const float*>(sp + soff[i]));
+        st.w[r][i] = load_stream16(wp + woff[i]);
+        st.sc[r][i] = __builtin_nontemporal_load(reinterpret_cast<const float*>(sp + soff[i]));
       }
     }
   };
   // epilogue operands of group g, requested with the weights (a load inside the epilogue
   // would have to wait for every weight request before it)
-  auto issue_aux = [&](W4Step& b, int g) {
+  auto issue_aux = [&](W4Step<B>& st, int g) {
     const int gg = g < n_groups ? g : 0;
-    b.aux[0] = 0; b.aux[1] = 0;
-    if constexpr (E == E_RESIDUAL) {
-      b.aux[0] = *reinterpret_cast<const unsigned int*>(p.res + 2 * gg + vzero);   // rows 2g, 2g + 1
-    } else if constexpr (E == E_QKV_ROPE) {
-      const int hh = p.head_dim >> 1;
-      const int rot_groups = ((p.n_q_heads + p.n_kv_heads) * p.head_dim) >> 1;
-      const int pc = pos_raw < 0 ? 0 : (pos_raw >= p.l_max ? p.l_max - 1 : pos_raw);
-      const int j = gg < rot_groups ? gg % hh : 0;
-      b.aux[0] = __float_as_uint(p.cos_tab[static_cast<size_t>(pc) * hh + j + vzero]);
-      b.aux[1] = __float_as_uint(p.sin_tab[static_cast<size_t>(pc) * hh + j + vzero]);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      st.aux[b][0] = 0; st.aux[b][1] = 0;
+      if constexpr (E == E_RESIDUAL) {   // rows 2g, 2g + 1 of x row b
+        st.aux[b][0] = *reinterpret_cast<const unsigned int*>(p.res + static_cast<size_t>(b) * p.N + 2 * gg + vzero);
+      } else if constexpr (E == E_QKV_ROPE) {
+        const int hh = p.head_dim >> 1;
+        const int rot_groups = ((p.n_q_heads + p.n_kv_heads) * p.head_dim) >> 1;
+        const int pc = pos_raw[b] < 0 ? 0 : (pos_raw[b] >= p.l_max ? p.l_max - 1 : pos_raw[b]);
+        const int j = gg < rot_groups ? gg % hh : 0;
+        st.aux[b][0] = __float_as_uint(p.cos_tab[static_cast<size_t>(pc) * hh + j + vzero]);
+        st.aux[b][1] = __float_as_uint(p.sin_tab[static_cast<size_t>(pc) * hh + j + vzero]);
+      }
     }
   };
 
   // ---- the first requests: x and the norm weights (they gate the prologue), then two steps of weights
-  constexpr int XC = 3;   // x chunks per thread: K <= 3 * 512 * 8
-  u32x4_t xr[XC], nwt[XC];
+  constexpr int XC = 3;   // x chunks per thread and row: K <= 3 * 512 * 8
+  u32x4_t xr[B][XC], nwt[XC];
 #pragma unroll
   for (int i = 0; i < XC; ++i) {
     const int c = tid + i * W4R_WAVES * 64;
     const int cc = c < nchunk ? c : 0;
-    xr[i] = load16(p.x + cc * 8);
+#pragma unroll
+    for (int b = 0; b < B; ++b) xr[b][i] = load16(p.x + static_cast<size_t>(b) * p.K + cc * 8);
     if constexpr (P == P_RMSNORM) nwt[i] = load16(p.norm_w + cc * 8);
     else nwt[i] = u32x4_t{0, 0, 0, 0};
   }
-  W4Step b0, b1;
+  W4Step<B> b0, b1;
   int g0 = gw, s0 = 0;          // the step held in b0
   int g1 = gw, s1 = 1;          // the step held in b1
   if (s1 == nslab) { s1 = 0; g1 += nw; }
@@ -1230,53 +1244,60 @@ __global__ __launch_bounds__(W4R_WAVES * 64, 2) void gemv_w4_row1_kernel(GemvPar
     for (int i = 0; i < 8; ++i) dst[i] = u32x4_t{v, v, v, v};
   }
 
-  // ---- x image (fused RMSNorm in HF order: round x * rstd to bf16, then multiply by the bf16 weight)
-  if constexpr (P == P_RMSNORM) {
-    float ss = 0.f;
+  // ---- x images (fused RMSNorm in HF order: round x * rstd to bf16, then multiply by the bf16 weight)
 #pragma unroll
-    for (int i = 0; i < XC; ++i) {
-      if (tid + i * W4R_WAVES * 64 < nchunk) {
+  for (int b = 0; b < B; ++b) {
+    u32x4_t* xs = reinterpret_cast<u32x4_t*>(xs_bytes + b * x_bytes);
+    if constexpr (P == P_RMSNORM) {
+      float ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float lo = bf16lo(xr[i][j]), hi = bf16hi(xr[i][j]);
-          ss += lo * lo + hi * hi;
+      for (int i = 0; i < XC; ++i) {
+        if (tid + i * W4R_WAVES * 64 < nchunk) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float lo = bf16lo(xr[b][i][j]), hi = bf16hi(xr[b][i][j]);
+            ss += lo * lo + hi * hi;
+          }
         }
       }
-    }
-    ss = block_sum(ss, red);
-    const float rstd = rsqrtf(ss / static_cast<float>(p.K) + p.eps);
+      ss = block_sum(ss, red);
+      const float rstd = rsqrtf(ss / static_cast<float>(p.K) + p.eps);
 #pragma unroll
-    for (int i = 0; i < XC; ++i) {
-      const int c = tid + i * W4R_WAVES * 64;
-      u32x4_t o;
+      for (int i = 0; i < XC; ++i) {
+        const int c = tid + i * W4R_WAVES * 64;
+        u32x4_t o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float lo = bf16_to_f32(f32_to_bf16(bf16lo(xr[i][j]) * rstd)) * bf16lo(nwt[i][j]);
-        const float hi = bf16_to_f32(f32_to_bf16(bf16hi(xr[i][j]) * rstd)) * bf16hi(nwt[i][j]);
-        o[j] = pack_bf16x2(lo, hi);
+        for (int j = 0; j < 4; ++j) {
+          const float lo = bf16_to_f32(f32_to_bf16(bf16lo(xr[b][i][j]) * rstd)) * bf16lo(nwt[i][j]);
+          const float hi = bf16_to_f32(f32_to_bf16(bf16hi(xr[b][i][j]) * rstd)) * bf16hi(nwt[i][j]);
+          o[j] = pack_bf16x2(lo, hi);
+        }
+        if (c < nchunk) xs[xs_slot<1>(c)] = w4_x_image(o);
       }
-      if (c < nchunk) xs[xs_slot<1>(c)] = w4_x_image(o);
-    }
-  } else {
+    } else {
 #pragma unroll
-    for (int i = 0; i < XC; ++i) {
-      const int c = tid + i * W4R_WAVES * 64;
-      if (c < nchunk) xs[xs_slot<1>(c)] = w4_x_image(xr[i]);
+      for (int i = 0; i < XC; ++i) {
+        const int c = tid + i * W4R_WAVES * 64;
+        if (c < nchunk) xs[xs_slot<1>(c)] = w4_x_image(xr[b][i]);
+      }
     }
   }
   __syncthreads();   // the last barrier: no wave waits for another below
 
   const unsigned char* tab_lane = tab + (lane & 31) * 4;
-  float acc[2] = {0.f, 0.f};
+  float acc[2][B];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
 
-  // Where this lane's four x chunks of iteration 0 sit in the image (bytes); iteration i of slab s
+  // Where this lane's four x chunks of iteration 0 sit in an image (bytes); iteration i of slab s
   // is (s * W4R_NI + i) * 4096 bytes on: the swizzle of xs_slot depends on the lane alone.
   unsigned int xoff[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) xoff[j] = static_cast<unsigned int>(xs_slot<1>(4 * lane + j)) * 16u;
-  const unsigned char* xs_bytes = reinterpret_cast<const unsigned char*>(xs);
 
-  // One step = four batches (iteration, row) of 16 lookups and 16 v_dot2c.  The lookups of a
+  // One step = four batches (iteration, row) of 16 lookups and 16 B v_dot2c.  The lookups of a
   // batch are issued a batch ahead of their dot products, behind fences the scheduler may not
   // move code across: left alone it emits eight lookups, waits for them and runs eight dependent
   // dot products, and the LDS round trip of every such group (sixteen per step) is exposed.
@@ -1288,19 +1309,29 @@ __global__ __launch_bounds__(W4R_WAVES * 64, 2) void gemv_w4_row1_kernel(GemvPar
 #pragma unroll
       for (int k = 0; k < 4; ++k) e[4 * j + k] = w4_lookup(tab_lane, w[j], k);
   };
-  auto dots = [&](const unsigned int (&e)[16], const u32x4_t (&xv)[4], float scale, float& a) {
-    float s0 = 0.f, s1 = 0.f;   // two chains: a v_dot2c does not wait for the one before it
+  auto xread = [&](u32x4_t (&xv)[B][4], unsigned int xit) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s0 = dot2_bf16(e[4 * j + 0], xv[j][0], s0);
-      s1 = dot2_bf16(e[4 * j + 1], xv[j][1], s1);
-      s0 = dot2_bf16(e[4 * j + 2], xv[j][2], s0);
-      s1 = dot2_bf16(e[4 * j + 3], xv[j][3], s1);
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        xv[b][j] = *reinterpret_cast<const u32x4_t*>(xs_bytes + b * x_bytes + xit + xoff[j]);
+  };
+  auto dots = [&](const unsigned int (&e)[16], const u32x4_t (&xv)[B][4], float scale, float (&a)[B]) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      float s0 = 0.f, s1 = 0.f;   // two chains: a v_dot2c does not wait for the one before it
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s0 = dot2_bf16(e[4 * j + 0], xv[b][j][0], s0);
+        s1 = dot2_bf16(e[4 * j + 1], xv[b][j][1], s1);
+        s0 = dot2_bf16(e[4 * j + 2], xv[b][j][2], s0);
+        s1 = dot2_bf16(e[4 * j + 3], xv[b][j][3], s1);
+      }
+      a[b] = fmaf(scale, s0 + s1, a[b]);
     }
-    a = fmaf(scale, s0 + s1, a);
   };
   static_assert(W4R_NI == 2, "the batch schedule below is written out for two iterations per step");
-  auto consume = [&](const W4Step& b, int slab) {
+  auto consume = [&](const W4Step<B>& st, int slab) {
     bool ok[2];
     unsigned int xit[2];
 #pragma unroll
@@ -1309,83 +1340,112 @@ __global__ __launch_bounds__(W4R_WAVES * 64, 2) void gemv_w4_row1_kernel(GemvPar
       ok[i] = it * 64 + lane < nwc;
       xit[i] = ok[i] ? static_cast<unsigned int>(it) * 4096u : 0u;
     }
-    u32x4_t xv0[4], xv1[4];
     unsigned int ea[16], eb[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) xv0[j] = *reinterpret_cast<const u32x4_t*>(xs_bytes + xit[0] + xoff[j]);
-    lookups(b.w[0][0], ea);
-    __builtin_amdgcn_sched_barrier(0);
-    lookups(b.w[1][0], eb);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) xv1[j] = *reinterpret_cast<const u32x4_t*>(xs_bytes + xit[1] + xoff[j]);
-    __builtin_amdgcn_sched_barrier(0);
-    dots(ea, xv0, ok[0] ? b.sc[0][0] : 0.f, acc[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    lookups(b.w[0][1], ea);
-    __builtin_amdgcn_sched_barrier(0);
-    dots(eb, xv0, ok[0] ? b.sc[1][0] : 0.f, acc[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    lookups(b.w[1][1], eb);
-    __builtin_amdgcn_sched_barrier(0);
-    dots(ea, xv1, ok[1] ? b.sc[0][1] : 0.f, acc[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    dots(eb, xv1, ok[1] ? b.sc[1][1] : 0.f, acc[1]);
+    if constexpr (B == 1) {
+      u32x4_t xv0[B][4], xv1[B][4];
+      xread(xv0, xit[0]);
+      lookups(st.w[0][0], ea);
+      __builtin_amdgcn_sched_barrier(0);
+      lookups(st.w[1][0], eb);
+      xread(xv1, xit[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      dots(ea, xv0, ok[0] ? st.sc[0][0] : 0.f, acc[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      lookups(st.w[0][1], ea);
+      __builtin_amdgcn_sched_barrier(0);
+      dots(eb, xv0, ok[0] ? st.sc[1][0] : 0.f, acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      lookups(st.w[1][1], eb);
+      __builtin_amdgcn_sched_barrier(0);
+      dots(ea, xv1, ok[1] ? st.sc[0][1] : 0.f, acc[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      dots(eb, xv1, ok[1] ? st.sc[1][1] : 0.f, acc[1]);
+    } else {
+      // more x rows: one set of x registers, re-read for the second iteration after its last use for the first
+      u32x4_t xv[B][4];
+      xread(xv, xit[0]);
+      lookups(st.w[0][0], ea);
+      __builtin_amdgcn_sched_barrier(0);
+      lookups(st.w[1][0], eb);
+      __builtin_amdgcn_sched_barrier(0);
+      dots(ea, xv, ok[0] ? st.sc[0][0] : 0.f, acc[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      lookups(st.w[0][1], ea);
+      __builtin_amdgcn_sched_barrier(0);
+      dots(eb, xv, ok[0] ? st.sc[1][0] : 0.f, acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      xread(xv, xit[1]);
+      lookups(st.w[1][1], eb);
+      __builtin_amdgcn_sched_barrier(0);
+      dots(ea, xv, ok[1] ? st.sc[0][1] : 0.f, acc[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      dots(eb, xv, ok[1] ? st.sc[1][1] : 0.f, acc[1]);
+    }
   };
 
   // the row sums of group g are complete: epilogue by lane 0 (stores only)
-  auto finish = [&](const W4Step& b, int g) {
-    const float a0 = wave_sum(acc[0]), a1 = wave_sum(acc[1]);
-    acc[0] = 0.f; acc[1] = 0.f;
+  auto finish = [&](const W4Step<B>& st, int g) {
+    float a0[B], a1[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      a0[b] = wave_sum(acc[0][b]); a1[b] = wave_sum(acc[1][b]);
+      acc[0][b] = 0.f; acc[1][b] = 0.f;
+    }
     if (lane != 0) return;
     int row[2];
     w4r_group_rows<E>(p, g, row);
-    if constexpr (E == E_STORE) {
-      const float a[2] = {a0, a1};
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        if (p.yf) p.yf[row[r]] = a[r];
-        else p.y[row[r]] = f32_to_bf16(a[r]);
-      }
-    } else if constexpr (E == E_RESIDUAL) {
-      const float a[2] = {a0, a1};
-      const float res[2] = {bf16lo(b.aux[0]), bf16hi(b.aux[0])};
-      unsigned int out = 0;
+    for (int b = 0; b < B; ++b) {
+      if constexpr (E == E_STORE) {
+        const float a[2] = {a0[b], a1[b]};
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const float sum = bf16_to_f32(f32_to_bf16(a[r])) + res[r];
-        out |= static_cast<unsigned int>(__builtin_bit_cast(unsigned short, f32_to_bf16(sum))) << (16 * r);
-      }
-      *reinterpret_cast<unsigned int*>(p.y + row[0]) = out;
-    } else if constexpr (E == E_SWIGLU) {
-      const float gate = bf16_to_f32(f32_to_bf16(a0)), up = bf16_to_f32(f32_to_bf16(a1));
-      p.y[row[0]] = f32_to_bf16(silu_f(gate) * up);
-    } else if constexpr (E == E_QKV_ROPE) {
-      const int hd = p.head_dim, hh = hd >> 1;
-      const int q_rows = p.n_q_heads * hd, k_rows = p.n_kv_heads * hd;
-      // the position is a device counter: clamp it into the cache so a sequence that ran
-      // past its capacity overwrites the last slot instead of writing outside the allocation
-      const int pos = pos_raw < 0 ? 0 : (pos_raw >= p.l_max ? p.l_max - 1 : pos_raw);
-      const bool kv_ok = !p.rows_one_seq || (pos_raw >= 0 && pos_raw < p.l_max);
-      if (row[0] < q_rows + k_rows) {
-        const int h_all = row[0] / hd, j = row[0] - h_all * hd;   // j < hh
-        bf16_t* dst;
-        if (h_all < p.n_q_heads) {
-          dst = p.q_out + h_all * hd;
-        } else {
-          if (!kv_ok) return;
-          dst = p.k_cache + (static_cast<size_t>(h_all - p.n_q_heads) * p.l_max + pos) * hd;
+        for (int r = 0; r < 2; ++r) {
+          if (p.yf) p.yf[static_cast<size_t>(b) * p.N + row[r]] = a[r];
+          else p.y[static_cast<size_t>(b) * p.N + row[r]] = f32_to_bf16(a[r]);
         }
-        const float c = __uint_as_float(b.aux[0]), sn = __uint_as_float(b.aux[1]);
-        const float x1 = bf16_to_f32(f32_to_bf16(a0)), x2 = bf16_to_f32(f32_to_bf16(a1));
-        dst[j] = f32_to_bf16(x1 * c - x2 * sn);
-        dst[j + hh] = f32_to_bf16(x2 * c + x1 * sn);
-      } else {
-        if (!kv_ok) return;
-        const int vr = row[0] - q_rows - k_rows;
-        const int h = vr / hd, j = vr - h * hd;
-        bf16_t* dst = p.v_cache + (static_cast<size_t>(h) * p.l_max + pos) * hd;
-        dst[j] = f32_to_bf16(a0);
-        dst[j + 1] = f32_to_bf16(a1);
+      } else if constexpr (E == E_RESIDUAL) {
+        const float a[2] = {a0[b], a1[b]};
+        const float res[2] = {bf16lo(st.aux[b][0]), bf16hi(st.aux[b][0])};
+        unsigned int out = 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const float sum = bf16_to_f32(f32_to_bf16(a[r])) + res[r];
+          out |= static_cast<unsigned int>(__builtin_bit_cast(unsigned short, f32_to_bf16(sum))) << (16 * r);
+        }
+        *reinterpret_cast<unsigned int*>(p.y + static_cast<size_t>(b) * p.N + row[0]) = out;
+      } else if constexpr (E == E_SWIGLU) {
+        const float gate = bf16_to_f32(f32_to_bf16(a0[b])), up = bf16_to_f32(f32_to_bf16(a1[b]));
+        p.y[static_cast<size_t>(b) * (p.N >> 1) + row[0]] = f32_to_bf16(silu_f(gate) * up);
+      } else if constexpr (E == E_QKV_ROPE) {
+        const int hd = p.head_dim, hh = hd >> 1;
+        const int q_rows = p.n_q_heads * hd, k_rows = p.n_kv_heads * hd;
+        // the position is a device counter: clamp it into the cache so a sequence that ran
+        // past its capacity overwrites the last slot instead of writing outside the allocation
+        const int pos = pos_raw[b] < 0 ? 0 : (pos_raw[b] >= p.l_max ? p.l_max - 1 : pos_raw[b]);
+        const int slot = p.rows_one_seq ? 0 : b;   // cache slot of this row's sequence
+        // a row past the cache of a multi-row pass is dropped, never wrapped onto a live slot
+        const bool kv_ok = !p.rows_one_seq || (pos_raw[b] >= 0 && pos_raw[b] < p.l_max);
+        if (row[0] < q_rows + k_rows) {
+          const int h_all = row[0] / hd, j = row[0] - h_all * hd;   // j < hh
+          bf16_t* dst;
+          if (h_all < p.n_q_heads) {
+            dst = p.q_out + static_cast<size_t>(b) * q_rows + h_all * hd;
+          } else {
+            if (!kv_ok) continue;
+            dst = p.k_cache + ((static_cast<size_t>(slot) * p.n_kv_heads + (h_all - p.n_q_heads)) * p.l_max + pos) * hd;
+          }
+          const float c = __uint_as_float(st.aux[b][0]), sn = __uint_as_float(st.aux[b][1]);
+          const float x1 = bf16_to_f32(f32_to_bf16(a0[b])), x2 = bf16_to_f32(f32_to_bf16(a1[b]));
+          dst[j] = f32_to_bf16(x1 * c - x2 * sn);
+          dst[j + hh] = f32_to_bf16(x2 * c + x1 * sn);
+        } else {
+          if (!kv_ok) continue;
+          const int vr = row[0] - q_rows - k_rows;
+          const int h = vr / hd, j = vr - h * hd;
+          bf16_t* dst = p.v_cache + ((static_cast<size_t>(slot) * p.n_kv_heads + h) * p.l_max + pos) * hd;
+          dst[j] = f32_to_bf16(a0[b]);
+          dst[j + 1] = f32_to_bf16(a1[b]);
+        }
       }
     }
   };
@@ -1421,26 +1481,42 @@ __global__ __launch_bounds__(W4R_WAVES * 64, 2) void gemv_w4_row1_kernel(GemvPar
   }
 }
 
-// shapes the one-row 4-bit kernel takes: row pairs, whole scale blocks, the table and the x
-// image inside the 64 KB a launch may ask for without opting in
-static bool w4_row1_ok(const GemvParams& p, int B, int E) {
+// shapes the 4-bit rows kernel takes: 1..3 x rows, row pairs, whole scale blocks, the table and the x
+// images inside a CU's LDS
+static bool w4_rows_ok(const GemvParams& p, int B, int E) {
   static const bool on = [] { const char* e = getenv("EVGPT_W4_ROW1"); return !e || atoi(e) != 0; }();
-  if (!on || B != 1 || !p.absmax || E == E_LOGITS) return false;
+  static const int max_b = [] { const char* e = getenv("EVGPT_W4_ROWS_MAX"); return e ? atoi(e) : 3; }();
+  if (!on || B < 1 || B > 3 || B > max_b || !p.absmax || E == E_LOGITS) return false;
   if (p.bias || p.act != ACT_NONE) return false;   // no load may sit in this kernel's epilogue
   if (p.N % 2 != 0 || p.K % 64 != 0) return false;
   if (E == E_QKV_ROPE && p.head_dim % 2 != 0) return false;
+  if (64 + W4_TAB_BYTES + static_cast<size_t>(B) * p.K * 2 > 128 * 1024) return false;
   return p.K <= 3 * W4R_WAVES * 64 * 8;   // the x chunks a block keeps in registers through the norm
 }
 
-template <int P, int E>
-static void launch_w4_row1(const GemvParams& p, hipStream_t st) {
-  const size_t smem = 64 + W4_TAB_BYTES + static_cast<size_t>(p.K) * 2;
-  // two blocks per CU hold their tables and x images at once; fewer blocks when there are
-  // fewer row pairs than waves
+template <int P, int E, int B>
+static void launch_w4_rows_b(const GemvParams& p, hipStream_t st) {
+  const size_t smem = 64 + W4_TAB_BYTES + static_cast<size_t>(B) * p.K * 2;
+  // one block per CU (two would hold their tables and x images at once; 256 measured ahead of 512);
+  // fewer blocks when there are fewer row pairs than waves
   static const int cap = [] { const char* e = getenv("EVGPT_W4_ROW1_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
+  static const bool attr = [] {   // more than the 64 KB a launch may ask for without opting in (two or three long x rows)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_w4_rows_kernel<P, E, B>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+  }();
+  (void)attr;
   const int groups = p.N >> 1;
   const int want = (groups + W4R_WAVES - 1) / W4R_WAVES;
-  hipLaunchKernelGGL((gemv_w4_row1_kernel<P, E>), dim3(want < cap ? want : cap), dim3(W4R_WAVES * 64), smem, st, p);
+  hipLaunchKernelGGL((gemv_w4_rows_kernel<P, E, B>), dim3(want < cap ? want : cap), dim3(W4R_WAVES * 64), smem, st, p);
+}
+
+template <int P, int E>
+static void launch_w4_rows(const GemvParams& p, int B, hipStream_t st) {
+  switch (B) {
+    case 1: launch_w4_rows_b<P, E, 1>(p, st); break;
+    case 2: launch_w4_rows_b<P, E, 2>(p, st); break;
+    default: launch_w4_rows_b<P, E, 3>(p, st); break;
+  }
 }
 
 static int g_forced_ks = 0;
@@ -1551,8 +1627,8 @@ template <int P, int E>
 static void launch_b(const GemvParams& p, int B, hipStream_t st) {
   if constexpr (E == E_LOGITS) {
     launch_bk<P, E, 1, 0>(p, B, st);
-  } else if (w4_row1_ok(p, B, E)) {
-    launch_w4_row1<P, E>(p, st);
+  } else if (w4_rows_ok(p, B, E)) {
+    launch_w4_rows<P, E>(p, B, st);
   } else if (p.absmax) {
     // a 4-bit row is a quarter of the bytes, so half the waves per unit keep the per-wave
     // work (and the share of a block's prologue) comparable; measured on the 7B decode
