@@ -1113,34 +1113,47 @@ __device__ __forceinline__ void w4r_group_rows(const GemvParams& p, int g, int (
   }
 }
 
-template <int B>
-struct W4Step {
-  u32x4_t w[2][W4R_NI];
-  float sc[2][W4R_NI];
+#ifndef EVGPT_ROWS_BF16_DEFAULT
+// bit b: b x rows of bf16 weights go to the rows kernel.  7B decode step, ms, the kernels it replaces vs this
+// one: 1 row 2.549 / 2.584 (gemv_row1_kernel stays), 2 rows 2.929 / 2.789, 3 rows 3.334 / 3.057, 4 rows 3.606
+// (few-row GEMM path) / 3.389.
+#define EVGPT_ROWS_BF16_DEFAULT 28
+#endif
+constexpr int ROWS_NI_BF16 = 4;   // bf16 weights: 64-lane chunk-iterations (512 weights each) per step
+template <int B, int NI>
+struct RowsStep {
+  u32x4_t w[2][NI];
+  float sc[2][NI];          // 4-bit weights only
   unsigned int aux[B][2];   // epilogue operands of the group, per x row: residual pair / cos, sin bits
 };
 
-// B x rows (1..3: the single-stream step, short speculative verifies, two or three streams) share every
-// lookup: a code byte is looked up once and multiplied into B sums.
-template <int P, int E, int B>
-__global__ __launch_bounds__(W4R_WAVES * 64, B == 1 ? 2 : 1) void gemv_w4_rows_kernel(GemvParams p) {
-  static_assert(E != E_LOGITS, "the LM head is not quantised");
-  static_assert(B >= 1 && B <= 3, "x rows");
+// B x rows (the single-stream step, short speculative verifies, a few streams) share every weight
+// register -- with 4-bit weights every lookup: a code byte is looked up once and multiplied into B sums.
+// Q = 0 streams bf16 weights through the same pipeline (no table, plain x images, one 16-byte x chunk
+// per 16 bytes of weights and x row).
+template <int P, int E, int B, int Q>
+__global__ __launch_bounds__(W4R_WAVES * 64, (B == 1 && Q) ? 2 : 1) void gemv_rows_kernel(GemvParams p) {
+  static_assert(E != E_LOGITS, "the LM head has a kernel of its own");
+  static_assert(B >= 1 && B <= 4 && (Q == 0 || B <= 3), "x rows");
+  constexpr bool W4 = Q != 0;
+  constexpr int NI = W4 ? W4R_NI : ROWS_NI_BF16;   // chunk-iterations per step
+  constexpr int IT_SHIFT = W4 ? 5 : 3;             // weights per 16-byte chunk: 32 / 8
+  using Step = RowsStep<B, NI>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // LDS carve: [block-sum scratch 64 B][table 32 KB][B x images of K * 2 B]
+  // LDS carve: [block-sum scratch 64 B][table 32 KB (4-bit)][B x images of K * 2 B]
   float* red = reinterpret_cast<float*>(smem);
   const unsigned char* tab = smem + 64;
-  unsigned char* xs_bytes = smem + 64 + W4_TAB_BYTES;
+  unsigned char* xs_bytes = smem + 64 + (W4 ? W4_TAB_BYTES : 0);
   const unsigned int x_bytes = static_cast<unsigned int>(p.K) * 2u;   // one image
   // the wave index as a scalar: everything derived from it (this wave's rows, its step count,
   // the loop below) is then uniform to the compiler, which branches instead of masking lanes
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nchunk = p.K >> 3;   // 16-byte chunks of x
-  const int nwc = p.K >> 5;      // 16-byte chunks of one weight row
-  const int nblk = p.K >> 6;     // scales per weight row
-  const size_t row_bytes = static_cast<size_t>(p.K >> 1);
+  const int nwc = p.K >> IT_SHIFT;   // 16-byte chunks of one weight row
+  const int nblk = p.K >> 6;         // scales per weight row (4-bit)
+  const size_t row_bytes = W4 ? static_cast<size_t>(p.K >> 1) : static_cast<size_t>(p.K) * 2;
   const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
-  const int nslab = (nwc + 64 * W4R_NI - 1) / (64 * W4R_NI);
+  const int nslab = (nwc + 64 * NI - 1) / (64 * NI);
   const int n_groups = p.N >> 1;
   const int nw = gridDim.x * W4R_WAVES;
   const int gw = blockIdx.x * W4R_WAVES + wid;   // neighbouring waves stream neighbouring rows
@@ -1166,14 +1179,14 @@ __global__ __launch_bounds__(W4R_WAVES * 64, B == 1 ? 2 : 1) void gemv_w4_rows_k
 
   // Row bases are uniform (scalar registers); a lane adds an unsigned 32-bit offset, which is the
   // addressing form that needs no 64-bit vector arithmetic per load.
-  auto issue = [&](W4Step<B>& st, int g, int slab) {
+  auto issue = [&](Step& st, int g, int slab) {
     const bool live = g < n_groups;
     int row[2];
     w4r_group_rows<E>(p, live ? g : 0, row);
-    unsigned int woff[W4R_NI], soff[W4R_NI];
+    unsigned int woff[NI], soff[NI];
 #pragma unroll
-    for (int i = 0; i < W4R_NI; ++i) {
-      const int c = (slab * W4R_NI + i) * 64 + lane;
+    for (int i = 0; i < NI; ++i) {
+      const int c = (slab * NI + i) * 64 + lane;
       const int cc = live ? (c < nwc ? c : nwc - 1) : 0;   // lanes past the row re-read its last chunk and drop it
       woff[i] = static_cast<unsigned int>(cc) * 16u;
       soff[i] = static_cast<unsigned int>(cc >> 1) * 4u;
@@ -1181,17 +1194,19 @@ __global__ __launch_bounds__(W4R_WAVES * 64, B == 1 ? 2 : 1) void gemv_w4_rows_k
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const unsigned char* wp = Wb + static_cast<size_t>(row[r]) * row_bytes;
-      const unsigned char* sp = reinterpret_cast<const unsigned char*>(p.absmax + static_cast<size_t>(row[r]) * nblk);
 #pragma unroll
-      for (int i = 0; i < W4R_NI; ++i) {
-        st.w[r][i] = load_stream16(wp + woff[i]);
-        st.sc[r][i] = __builtin_nontemporal_load(reinterpret_cast<const float*>(sp + soff[i]));
+      for (int i = 0; i < NI; ++i) st.w[r][i] = load_stream16(wp + woff[i]);
+      if constexpr (W4) {
+        const unsigned char* sp = reinterpret_cast<const unsigned char*>(p.absmax + static_cast<size_t>(row[r]) * nblk);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          st.sc[r][i] = __builtin_nontemporal_load(reinterpret_cast<const float*>(sp + soff[i]));
       }
     }
   };
   // epilogue operands of group g, requested with the weights (a load inside the epilogue
   // would have to wait for every weight request before it)
-  auto issue_aux = [&](W4Step<B>& st, int g) {
+  auto issue_aux = [&](Step& st, int g) {
     const int gg = g < n_groups ? g : 0;
 #pragma unroll
     for (int b = 0; b < B; ++b) {
@@ -1221,7 +1236,7 @@ __global__ __launch_bounds__(W4R_WAVES * 64, B == 1 ? 2 : 1) void gemv_w4_rows_k
     if constexpr (P == P_RMSNORM) nwt[i] = load16(p.norm_w + cc * 8);
     else nwt[i] = u32x4_t{0, 0, 0, 0};
   }
-  W4Step<B> b0, b1;
+  Step b0, b1;
   int g0 = gw, s0 = 0;          // the step held in b0
   int g1 = gw, s1 = 1;          // the step held in b1
   if (s1 == nslab) { s1 = 0; g1 += nw; }
@@ -1235,7 +1250,7 @@ __global__ __launch_bounds__(W4R_WAVES * 64, B == 1 ? 2 : 1) void gemv_w4_rows_k
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- table: entry t = (value[t & 15], value[t >> 4]), 32 copies 4 bytes apart
-  if (tid < 256) {
+  if (W4 && tid < 256) {
     unsigned int e[4];
     w4_expand8(static_cast<unsigned int>(tid), p.code, e);   // weight 0 = code t & 15, weight 4 = code t >> 4
     const unsigned int v = (e[0] & 0xFFFFu) | (e[2] << 16);
@@ -1272,13 +1287,13 @@ __global__ __launch_bounds__(W4R_WAVES * 64, B == 1 ? 2 : 1) void gemv_w4_rows_k
           const float hi = bf16_to_f32(f32_to_bf16(bf16hi(xr[b][i][j]) * rstd)) * bf16hi(nwt[i][j]);
           o[j] = pack_bf16x2(lo, hi);
         }
-        if (c < nchunk) xs[xs_slot<1>(c)] = w4_x_image(o);
+        if (c < nchunk) xs[xs_slot<Q>(c)] = W4 ? w4_x_image(o) : o;
       }
     } else {
 #pragma unroll
       for (int i = 0; i < XC; ++i) {
         const int c = tid + i * W4R_WAVES * 64;
-        if (c < nchunk) xs[xs_slot<1>(c)] = w4_x_image(xr[b][i]);
+        if (c < nchunk) xs[xs_slot<Q>(c)] = W4 ? w4_x_image(xr[b][i]) : xr[b][i];
       }
     }
   }
@@ -1291,18 +1306,20 @@ __global__ __launch_bounds__(W4R_WAVES * 64, B == 1 ? 2 : 1) void gemv_w4_rows_k
 #pragma unroll
     for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
 
-  // Where this lane's four x chunks of iteration 0 sit in an image (bytes); iteration i of slab s
-  // is (s * W4R_NI + i) * 4096 bytes on: the swizzle of xs_slot depends on the lane alone.
+  // Where this lane's x chunks of iteration 0 sit in an image (bytes).  4-bit: four chunks per weight chunk,
+  // iteration i of slab s (s * NI + i) * 4096 bytes on (the swizzle of xs_slot depends on the lane alone);
+  // bf16: one chunk, 1024 bytes per iteration.
   unsigned int xoff[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) xoff[j] = static_cast<unsigned int>(xs_slot<1>(4 * lane + j)) * 16u;
+  for (int j = 0; j < 4; ++j) xoff[j] = W4 ? static_cast<unsigned int>(xs_slot<1>(4 * lane + j)) * 16u : lane * 16u;
 
-  // One step = four batches (iteration, row) of 16 lookups and 16 B v_dot2c.  The lookups of a
+  // 4-bit: one step = four batches (iteration, row) of 16 lookups and 16 B v_dot2c.  The lookups of a
   // batch are issued a batch ahead of their dot products, behind fences the scheduler may not
   // move code across: left alone it emits eight lookups, waits for them and runs eight dependent
   // dot products, and the LDS round trip of every such group (sixteen per step) is exposed.
   // No branch around the arithmetic either (a skipped wait is a wait the compiler repeats in
-  // full later): a lane past the end of the row multiplies its re-read chunk by a zero scale.
+  // full later): a lane past the end of the row multiplies its re-read chunk by a zero scale
+  // (bf16: its sum is dropped by a select).
   auto lookups = [&](const u32x4_t& w, unsigned int (&e)[16]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1330,8 +1347,31 @@ __global__ __launch_bounds__(W4R_WAVES * 64, B == 1 ? 2 : 1) void gemv_w4_rows_k
       a[b] = fmaf(scale, s0 + s1, a[b]);
     }
   };
-  static_assert(W4R_NI == 2, "the batch schedule below is written out for two iterations per step");
-  auto consume = [&](const W4Step<B>& st, int slab) {
+  static_assert(W4R_NI == 2, "the 4-bit batch schedule below is written out for two iterations per step");
+  auto consume = [&](const Step& st, int slab) {
+    if constexpr (!W4) {
+      // bf16: the x chunks of all iterations first (one LDS round trip per step), then the dot products
+      u32x4_t xv[NI][B];
+      bool ok[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int it = slab * NI + i;
+        ok[i] = it * 64 + lane < nwc;
+        const unsigned int xit = ok[i] ? static_cast<unsigned int>(it) * 1024u : 0u;
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+          xv[i][b] = *reinterpret_cast<const u32x4_t*>(xs_bytes + b * x_bytes + xit + xoff[0]);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int b = 0; b < B; ++b) {
+            const float t = dot8_bf16(st.w[r][i], xv[i][b], 0.f);
+            acc[r][b] += ok[i] ? t : 0.f;
+          }
+    } else {
     bool ok[2];
     unsigned int xit[2];
 #pragma unroll
@@ -1381,10 +1421,11 @@ __global__ __launch_bounds__(W4R_WAVES * 64, B == 1 ? 2 : 1) void gemv_w4_rows_k
       __builtin_amdgcn_sched_barrier(0);
       dots(eb, xv, ok[1] ? st.sc[1][1] : 0.f, acc[1]);
     }
+    }
   };
 
   // the row sums of group g are complete: epilogue by lane 0 (stores only)
-  auto finish = [&](const W4Step<B>& st, int g) {
+  auto finish = [&](const Step& st, int g) {
     float a0[B], a1[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
@@ -1481,41 +1522,58 @@ __global__ __launch_bounds__(W4R_WAVES * 64, B == 1 ? 2 : 1) void gemv_w4_rows_k
   }
 }
 
-// shapes the 4-bit rows kernel takes: 1..3 x rows, row pairs, whole scale blocks, the table and the x
-// images inside a CU's LDS
-static bool w4_rows_ok(const GemvParams& p, int B, int E) {
+// shapes the rows kernel takes: 1..3 x rows of 4-bit weights or (EVGPT_ROWS_BF16: the x rows it takes)
+// bf16 weights, row pairs, whole scale blocks, the table and the x images inside a CU's LDS
+static bool rows_kernel_ok(const GemvParams& p, int B, int E) {
   static const bool on = [] { const char* e = getenv("EVGPT_W4_ROW1"); return !e || atoi(e) != 0; }();
   static const int max_b = [] { const char* e = getenv("EVGPT_W4_ROWS_MAX"); return e ? atoi(e) : 3; }();
-  if (!on || B < 1 || B > 3 || B > max_b || !p.absmax || E == E_LOGITS) return false;
+  // bf16: bit b set = take b x rows
+  static const int bf16_rows = [] { const char* e = getenv("EVGPT_ROWS_BF16"); return e ? atoi(e) : EVGPT_ROWS_BF16_DEFAULT; }();
+  if (E == E_LOGITS || B < 1) return false;
+  if (p.absmax) {
+    if (!on || B > 3 || B > max_b) return false;
+    if (p.K % 64 != 0) return false;
+  } else {
+    if (B > 4 || !((bf16_rows >> B) & 1) || p.K % 8 != 0) return false;
+  }
   if (p.bias || p.act != ACT_NONE) return false;   // no load may sit in this kernel's epilogue
-  if (p.N % 2 != 0 || p.K % 64 != 0) return false;
+  if (p.N % 2 != 0) return false;
   if (E == E_QKV_ROPE && p.head_dim % 2 != 0) return false;
-  if (64 + W4_TAB_BYTES + static_cast<size_t>(B) * p.K * 2 > 128 * 1024) return false;
+  if (64 + (p.absmax ? W4_TAB_BYTES : 0) + static_cast<size_t>(B) * p.K * 2 > 128 * 1024) return false;
   return p.K <= 3 * W4R_WAVES * 64 * 8;   // the x chunks a block keeps in registers through the norm
 }
 
-template <int P, int E, int B>
-static void launch_w4_rows_b(const GemvParams& p, hipStream_t st) {
-  const size_t smem = 64 + W4_TAB_BYTES + static_cast<size_t>(B) * p.K * 2;
+template <int P, int E, int B, int Q>
+static void launch_rows_b(const GemvParams& p, hipStream_t st) {
+  const size_t smem = 64 + (Q ? W4_TAB_BYTES : 0) + static_cast<size_t>(B) * p.K * 2;
   // one block per CU (two would hold their tables and x images at once; 256 measured ahead of 512);
   // fewer blocks when there are fewer row pairs than waves
   static const int cap = [] { const char* e = getenv("EVGPT_W4_ROW1_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
-  static const bool attr = [] {   // more than the 64 KB a launch may ask for without opting in (two or three long x rows)
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_w4_rows_kernel<P, E, B>),
+  static const bool attr = [] {   // more than the 64 KB a launch may ask for without opting in (several long x rows)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_rows_kernel<P, E, B, Q>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
   }();
   (void)attr;
   const int groups = p.N >> 1;
   const int want = (groups + W4R_WAVES - 1) / W4R_WAVES;
-  hipLaunchKernelGGL((gemv_w4_rows_kernel<P, E, B>), dim3(want < cap ? want : cap), dim3(W4R_WAVES * 64), smem, st, p);
+  hipLaunchKernelGGL((gemv_rows_kernel<P, E, B, Q>), dim3(want < cap ? want : cap), dim3(W4R_WAVES * 64), smem, st, p);
 }
 
 template <int P, int E>
-static void launch_w4_rows(const GemvParams& p, int B, hipStream_t st) {
-  switch (B) {
-    case 1: launch_w4_rows_b<P, E, 1>(p, st); break;
-    case 2: launch_w4_rows_b<P, E, 2>(p, st); break;
-    default: launch_w4_rows_b<P, E, 3>(p, st); break;
+static void launch_rows(const GemvParams& p, int B, hipStream_t st) {
+  if (p.absmax) {
+    switch (B) {
+      case 1: launch_rows_b<P, E, 1, 1>(p, st); break;
+      case 2: launch_rows_b<P, E, 2, 1>(p, st); break;
+      default: launch_rows_b<P, E, 3, 1>(p, st); break;
+    }
+  } else {
+    switch (B) {
+      case 1: launch_rows_b<P, E, 1, 0>(p, st); break;
+      case 2: launch_rows_b<P, E, 2, 0>(p, st); break;
+      case 3: launch_rows_b<P, E, 3, 0>(p, st); break;
+      default: launch_rows_b<P, E, 4, 0>(p, st); break;
+    }
   }
 }
 
@@ -1627,8 +1685,8 @@ template <int P, int E>
 static void launch_b(const GemvParams& p, int B, hipStream_t st) {
   if constexpr (E == E_LOGITS) {
     launch_bk<P, E, 1, 0>(p, B, st);
-  } else if (w4_rows_ok(p, B, E)) {
-    launch_w4_rows<P, E>(p, B, st);
+  } else if (rows_kernel_ok(p, B, E)) {
+    launch_rows<P, E>(p, B, st);
   } else if (p.absmax) {
     // a 4-bit row is a quarter of the bytes, so half the waves per unit keep the per-wave
     // work (and the share of a block's prologue) comparable; measured on the 7B decode

@@ -521,7 +521,7 @@ class TensorParallelEngine(GenerationEngine):
 
     def _layers_step(self) -> None:
         raw = self.raw
-        if self.B <= 3:     # measured: the GEMV holds up to 3 rows (3.09 / 3.75 ms), 4 rows are faster as a GEMM
+        if self.B <= self.gemv_rows:     # measured: 2 / 3 / 4 streams 2.79 / 3.06 / 3.39 ms per step, 4 as a GEMM 3.61
             return super()._layers_step()
         # batched decode (e.g. 32 streams): M = B rows through the MFMA GEMM
         B = self.B

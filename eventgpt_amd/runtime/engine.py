@@ -320,9 +320,10 @@ class GenerationEngine:
         return x[0] if return_hidden else None
 
     # Up to gemv_rows rows of ONE sequence (short speculative verifies) run on the decode
-    # step's weight-streaming kernels: fused norm+QKV+RoPE+cache append, o_proj+residual,
+    # step's weight-streaming kernels (7B, 2 115 keys, ms per verify pass of 1 / 2 / 3 drafts: 3.03 / 3.23 /
+    # 3.47, the few-row GEMM path 3.16* / 3.49* / 3.67 -- * on the multi-row GEMV that preceded the rows kernel): fused norm+QKV+RoPE+cache append, o_proj+residual,
     # fused norm+gate/up+SwiGLU, down+residual: 4 launches + attention per layer.
-    gemv_rows = 3
+    gemv_rows = 4
 
     def _gemv_rows_ok(self, rows: int) -> bool:
         cap = int(self.raw.gemv_w4_max_batch() if self.w4 else self.raw.gemv_max_batch())
