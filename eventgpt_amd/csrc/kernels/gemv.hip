@@ -1537,7 +1537,12 @@ static bool rows_kernel_ok(const GemvParams& p, int B, int E) {
     // one row without the fused norm (o_proj, down_proj) goes here as well: 7B decode step, three alternating
     // runs, 2.548 -> 2.542 ms (the norm-fused projections measure the other way: 2.549 -> 2.584 with all four)
     static const int res1 = [] { const char* e = getenv("EVGPT_ROWS_BF16_RES1"); return e ? atoi(e) : 1; }();
-    const bool take = ((bf16_rows >> B) & 1) || (B == 1 && res1 && !p.norm_w && (E == E_RESIDUAL || E == E_STORE));
+    // bit E of EVGPT_ROWS_BF16_E1 sends one row with that epilogue here whatever the prologue.  7B decode step,
+    // two alternating runs: none 2.540 / 2.544, q|k|v (bit 3) 2.527 / 2.528, gate/up (bit 2) 2.545 / 2.544,
+    // both 2.539 / 2.537: q|k|v is 6 144 row pairs = three per wave exactly.
+    static const int e1 = [] { const char* e = getenv("EVGPT_ROWS_BF16_E1"); return e ? atoi(e) : 8; }();
+    const bool take = ((bf16_rows >> B) & 1) || (B == 1 && res1 && !p.norm_w && (E == E_RESIDUAL || E == E_STORE)) ||
+                      (B == 1 && ((e1 >> E) & 1));
     if (B > 4 || !take || p.K % 8 != 0) return false;
   }
   if (p.bias || p.act != ACT_NONE) return false;   // no load may sit in this kernel's epilogue
