@@ -94,6 +94,7 @@ struct GemmParams {
   int rope_hq, rope_hkv, rope_lmax;
   // row tiles per group of the tile walk (0: whole columns); set by the launchers
   int group_m;
+  int rows_epilogue;   // 8-wave kernel: bf16 output stored as whole lines through LDS (set by launch_256)
   // 4-wave kernel with split K: workgroup index = split * tiles + tile instead of tile * splits + split
   int split_major;
 };
@@ -286,6 +287,68 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
         }
       }
     }
+  }
+}
+
+// bf16 output of the 8-wave kernel through LDS.  The MFMA layout gives a lane 4 consecutive columns of 16
+// rows, so a direct store instruction writes 16 pieces of 32 bytes in 16 cache lines and a wave's 128-byte
+// row segment arrives as four partial writes: a 256 x 256 tile is 4 096 of them, and with the stores left out
+// the kernel runs 23 080 x 4 096 x 1 024 at 1 143 instead of 778 TFLOP/s.  Here a wave writes 64 rows of its
+// 128 x 64 block to LDS (8 bytes per lane, 16-byte chunks XOR-swizzled by the row), reads them back as 16 bytes
+// per lane -- 8 lanes per row -- and stores 8 rows of 128 contiguous bytes per instruction; the residual is
+// added on the way out, read in the same whole lines.  The scratch is the wave's own staging slices (4 x 2 KB)
+// of the ring buffer the next tile's K-tile 1 goes to: nobody else writes them, the wave itself stages into
+// them after these stores have their data, and every reader is past the barrier that ended the K loop.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, f32x4_t (&acc)[TM][TN], int m0, int n0,
+                                                   int wr, int wc, int lane, unsigned char* scratch) {
+  static_assert(TM == 8 && TN == 4, "128 x 64 per wave");
+  const int frow = lane & 15, fq = lane >> 4;
+  const int rl = lane >> 3, cl = lane & 7;          // read side: row within 8, 16-byte chunk of the 128-byte row
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int il = 0; il < 4; ++il) {
+      const int i = pass * 4 + il;
+      unsigned char* slice = scratch + il * 16384;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + fq * 4;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (p.bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += bf16_to_f32(p.bias[n + r]);
+        }
+        if (p.act != ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
+        }
+        const u32x2_t w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        const int chunk = (j * 2 + (fq >> 1)) ^ (frow & 7);
+        *reinterpret_cast<u32x2_t*>(slice + frow * 128 + chunk * 16 + (fq & 1) * 8) = w;
+      }
+    }
+    // one wave's LDS operations execute in issue order; the compiler must keep them in this order too
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const unsigned char* slice = scratch + (q >> 1) * 16384;
+      const int r = (q & 1) * 8 + rl;
+      u32x4_t d = *reinterpret_cast<const u32x4_t*>(slice + r * 128 + ((cl ^ (r & 7)) << 4));
+      const int m = m0 + wr * 128 + pass * 64 + q * 8 + rl;
+      const int n = n0 + wc * 64 + cl * 8;
+      if (m < p.M && n < p.N) {           // N % 8 == 0: a chunk is inside or outside as a whole
+        const size_t o = static_cast<size_t>(m) * p.ldc + n;
+        if (p.res) {
+          const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(p.res + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            d[e] = pack_bf16x2(bf16lo(d[e]) + bf16lo(rv[e]), bf16hi(d[e]) + bf16hi(rv[e]));
+        }
+        *reinterpret_cast<u32x4_t*>(p.C + o) = d;
+      }
+    }
+    asm volatile("" ::: "memory");
   }
 }
 
@@ -793,7 +856,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
       locate(t, cur);
       stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
     }
-    gemm_epilogue<TM, TN, BM / 2, 64, 4>(p, acc, m0, n0, wr, wc, tn, tiles_n, ksplit, lane);
+    if constexpr (BMT == 256) {
+      // plain bf16 output with whole 16-byte chunks per row: whole-line stores through LDS
+      if (p.rows_epilogue) gemm_epilogue_rows<TM, TN>(p, acc, m0, n0, wr, wc, lane, smem + TILE + wid * 2048);
+      else gemm_epilogue<TM, TN, BM / 2, 64, 4>(p, acc, m0, n0, wr, wc, tn, tiles_n, ksplit, lane);
+    } else {
+      gemm_epilogue<TM, TN, BM / 2, 64, 4>(p, acc, m0, n0, wr, wc, tn, tiles_n, ksplit, lane);
+    }
     if (!more) break;
   }
 }
@@ -827,6 +896,11 @@ static void launch_256(const GemmParams& p, hipStream_t st) {
   const int grid = (g_persist_256 && tiles > cus) ? cus : tiles;
   GemmParams q = p;
   q.group_m = g_group_m;
+  static const bool rows_on = [] { const char* e = getenv("EVGPT_GEMM_ROWS_EPILOGUE"); return !e || atoi(e) != 0; }();
+  q.rows_epilogue = rows_on && BM == 256 && p.C && !p.Cf && !p.amax_val && !p.glu_half && p.splitk == 1 &&
+                    !p.raw_partial && !p.rope_cos && p.N % 8 == 0 && p.ldc % 8 == 0 &&
+                    (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
+                    (!p.res || (reinterpret_cast<uintptr_t>(p.res) & 15) == 0);
   hipLaunchKernelGGL((gemm256_kernel<AT, BT, BM>), dim3(grid), dim3(512), smem, st, q);
 }
 
@@ -901,7 +975,12 @@ void gemm_force_config(int cfg) { g_forced_cfg = cfg; }
 // 6688 x 4096 x 2048 980 vs 945, 23080 x 4096 x 2048 1102 vs 1003 and 4643 x 12288 x 4096 1253 vs 1070.
 static bool use_256(int M, int N, int K = 0) {
   const long long t = static_cast<long long>((M + 255) / 256) * ((N + 255) / 256);
-  if (K > 0 && !(K >= 4096 || (K >= 2048 && M >= 6144))) return false;
+  // (Those were measured with the direct epilogue.  With whole-line stores through LDS -- gemm_epilogue_rows --
+  // the 8-wave kernel is ahead over short contractions too once its tiles make more than half a round: 8-wave vs
+  // 128 x 128, 2885 x 3072 x 1024 (144 tiles) 603 vs 508, 2885 x 4096 x 256 347 vs 291, 4616 x 3072 x 1024
+  // 866 vs 667, 6688 x 4096 x 1024 961 vs 775, 11540 x 1024 x 1024 (184) 731 vs 634, 23080 x 4096 x 1024 879 vs
+  // 653; behind below that: 6688 x 1024 x 1024 (108 tiles) 463 vs 552, 4616 x 1024 x 4096 (76) 485 vs 627.)
+  if (K > 0 && !(K >= 4096 || (K >= 2048 && M >= 6144)) && t < 140) return false;
   // 768..1023 rows are three or four row tiles (up to a quarter of the last one empty): still ahead
   // once the tiles come near one round (836 x 12288 x 4096: 914 vs 833 TFLOP/s; K-strided W,
   // 836 x 11008 x 4096: 686 vs 582), behind for 64 tiles (836 x 4096: 338 vs 700)
