@@ -89,18 +89,26 @@ def run_config(model_fn, info, prompts, want_x, allreduce):
 def main(out_path):
     info = init_distributed(backend="gloo", use_gpu=True)
     dev = info.device
-    # head_dim stays 128; with more than four ranks the model gets one head per rank
-    heads = max(4, info.world)
-    cfg = EventChatConfig(vocab_size=515, hidden_size=128 * heads, intermediate_size=1408, num_hidden_layers=2,
-                          num_attention_heads=heads, max_position_embeddings=512)
+    wide = os.environ.get("EVGPT_TP_WORKER_GEOMETRY") == "7b"
+    if wide:
+        # two layers of the 7B decoder: a rank of eight multiplies by 1536 x 4096 (q|k|v), 4096 x 512 (o_proj),
+        # 2816 x 4096 (gate|up, 1376 columns padded to 1408), 4096 x 1408 (down) and 4001 vocabulary rows
+        cfg = EventChatConfig(vocab_size=32003, hidden_size=4096, intermediate_size=11008, num_hidden_layers=2,
+                              num_attention_heads=32, max_position_embeddings=512)
+    else:
+        # head_dim stays 128; with more than four ranks the model gets one head per rank
+        heads = max(4, info.world)
+        cfg = EventChatConfig(vocab_size=515, hidden_size=128 * heads, intermediate_size=1408, num_hidden_layers=2,
+                              num_attention_heads=heads, max_position_embeddings=512)
     H = cfg.hidden_size
     modes = ("rccl", "oneshot") if info.world == 2 else ("rccl",)   # the IPC all-reduce is exercised by two processes
     model_fn = lambda: EventChatModel.from_config(cfg, torch.bfloat16, dev, seed=3)   # noqa: E731
     out = {}
-    for B in (2, 6):
-        # two streams: short prompts, prefilled one by one; six streams: every prompt longer than 32
+    for B in ((1, 3, 6) if wide else (2, 6)):
+        # one stream (7B shards): one prompt of 150 rows through the prompt GEMMs, then the one-row step;
+        # two / three streams: short prompts, prefilled one by one; six streams: every prompt longer than 32
         # tokens, so they are prefilled as ONE pack (shared projections, per-slot attention)
-        base = 20 if B == 2 else 40
+        base = 150 if B == 1 else 20 if B <= 3 else 40
         prompts = [(torch.randn(base + 3 * b, H, device=dev, generator=torch.Generator(device=dev).manual_seed(b))
                     * 0.5).to(torch.bfloat16) for b in range(B)]
         want, want_x = reference(model_fn(), prompts)

@@ -311,6 +311,37 @@ def test_tensor_parallel_engine_more_ranks(tmp_path, world):
             assert got["cos_prefill"][b] > 0.999 and got["cos_step"][b] > 0.995, (key, got["cos_prefill"], got["cos_step"])
 
 
+@pytest.mark.timeout(300)
+def test_tensor_parallel_engine_on_shards_of_the_7b_decoder(tmp_path, world=4):
+    """The matrices a rank of four holds of the 7B decoder (q|k|v 3072 x 4096, o_proj 4096 x 1024, gate|up
+    5504 x 4096, down 4096 x 2752, 8001 vocabulary rows), two layers, through the prompt GEMMs, the one-row
+    step, the three-row step and the packed six-stream path.  The ranks share GPU 0 over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / f"tp_engine7b_{world}.json")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", EVGPT_TP_WORKER_GEOMETRY="7b")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29569 + world),
+           os.path.join(here, "_tp_engine_worker.py"), out]
+    print(f"launching {world}-rank TP engine worker on 7B shards", flush=True)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    allgot = json.load(open(out))
+    i_local = (11008 // world + 63) // 64 * 64
+    for key in ("b1_rccl", "b3_rccl", "b6_rccl"):
+        got = allgot[key]
+        assert got["heads_local"] == 32 // world and got["i_local"] == i_local and got["logits_width"] == 32003, key
+        assert len(got["ranks"]) == world and all(rk == got["ranks"][0] for rk in got["ranks"]), key
+        assert got["packed_prompts"] == (6 if key == "b6_rccl" else 0), (key, got["packed_prompts"])
+        assert got["logits_equal"], key
+        for b, want in enumerate(got["want"]):
+            assert got["first_tok"][b] == want[0] == got["ranks"][0][b][0], (key, b)
+            assert got["cos_prefill"][b] > 0.999 and got["cos_step"][b] > 0.995, (key, got["cos_prefill"], got["cos_step"])
+
+
 def test_continuous_batching_matches_single_stream(model, dev):
     """7 requests of different lengths and budgets through 3 slots: every request gets the
     tokens its own single-stream greedy decode produces, slots are reused, and sequences
