@@ -118,3 +118,50 @@ def test_lm_head_with_an_odd_row_count(rows):
     for r in range(6):
         b = int(pi6[r, int(pv6[r].argmax())])
         assert 0 <= b < rows and l6[r, b] >= l6[r].max() - 2e-2 * l6.abs().mean() - 1e-2 * l6[r].max().abs(), r
+
+
+@pytest.mark.parametrize("heads,inter", SHARDS)
+@pytest.mark.parametrize("M", [32, 636])
+def test_prompt_and_batch_gemms_on_narrow_matrices(heads, inter, M):
+    """The products of a 636-row prompt and of a 32-stream step: row-parallel projections over the short
+    contractions (plain, with residual, as one fp32 slab and as split-K slabs), the gated MLP input
+    projection with few columns, and q|k|v of few heads with rotation and cache append in the epilogue
+    against GEMM + rotation kernel."""
+    from eventgpt_amd import ops
+    from eventgpt_amd.ops import hip
+    raw = hip.raw
+    for K in (heads * D, inter):
+        w = _rand((H, K), K + 1, 0.03)
+        x = _rand((M, K), 23, 0.5)
+        res = _rand((M, H), 24)
+        ref = x.float() @ w.float().t()
+        _close(raw.linear(x, w, None, None, 0, False), ref, ("linear", M, K))
+        _close(raw.linear(x, w, None, res, 0, False), ref + res.float(), ("linear+res", M, K))
+        for nslab in (1, None):
+            part = raw.linear_partial(x, w, 1) if nslab else raw.linear_partial(x, w)
+            assert part.dtype == torch.float32 and part.shape[1:] == (M, H) and (nslab is None or part.shape[0] == 1)
+            got = part.sum(0)
+            assert (got - ref).abs().max() <= 2e-3 * ref.abs().mean() + 2e-3 * ref.abs().max(), (M, K, nslab)
+    w_gu = _rand((2 * inter, H), 25, 0.03)
+    xn = _rand((M, H), 26, 0.5)
+    gu = xn.float() @ w_gu.float().t()
+    want = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
+    if M > 32:
+        _close(raw.linear_swiglu(xn, w_gu), want, ("linear_swiglu", M, inter), tol=3e-2)
+    _close(raw.reduce_swiglu(raw.linear_partial(xn, w_gu)), want, ("reduce_swiglu", M, inter), tol=3e-2)
+    if M > 32:
+        L = 768
+        w_qkv = _rand((3 * heads * D, H), 27, 0.03)
+        cos, sin = ops.rope_tables(L, D, 10000.0, _dev())
+        pos0 = torch.tensor([9], dtype=torch.int32, device=_dev())
+        q = torch.zeros(1, M, heads, D, dtype=torch.bfloat16, device=_dev())
+        kc = torch.zeros(1, heads, L, D, dtype=torch.bfloat16, device=_dev())
+        vc = torch.zeros_like(kc)
+        assert raw.linear_qkv_rope(xn, w_qkv, q, kc, vc, cos, sin, pos0, heads, heads)
+        qkv = raw.linear(xn, w_qkv, None, None, 0, False).view(1, M, -1)
+        q1, k1, v1 = torch.zeros_like(q), torch.zeros_like(kc), torch.zeros_like(vc)
+        raw.prefill_rope_kv(qkv, q1, k1, v1, cos, sin, pos0, heads, heads, D)
+        for a, b, what in ((q, q1, "q"), (kc, k1, "k"), (vc, v1, "v")):     # (the two GEMMs may tile differently)
+            assert (a.float() - b.float()).abs().max() <= 0.02 * b.float().abs().max() + 1e-3, what
+            assert torch.equal(a == 0, b == 0), what
+        assert k1[0, :, 9:9 + M].abs().sum() > 0 and k1[0, :, 9 + M:].abs().sum() == 0
