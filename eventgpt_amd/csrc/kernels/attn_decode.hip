@@ -16,11 +16,12 @@ constexpr int AD_WAVES = 4;
 
 // part_o : [B][Hq][nsplit][D] fp32, un-normalised
 // part_ml: [B][Hq][nsplit][2] fp32 (running max, running sum)
-template <int D>
+// FINAL (one split): the block holds the whole row and writes the normalised output itself.
+template <int D, bool FINAL = false>
 __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_split_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k_cache,
     const bf16_t* __restrict__ v_cache, float* __restrict__ part_o, float* __restrict__ part_ml,
-    const int* __restrict__ pos, int Hq, int Hkv, int l_max, float scale) {
+    const int* __restrict__ pos, int Hq, int Hkv, int l_max, float scale, bf16_t* __restrict__ out) {
   constexpr int LPK = D / 8;       // lanes per key row
   constexpr int KPW = 64 / LPK;    // keys per wave-instruction
   const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z, nsplit = gridDim.y;
@@ -107,9 +108,13 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_split_kernel(
       ll += s_l[w] * c;
       oo += s_o[w][tid] * c;
     }
-    const size_t pi = (static_cast<size_t>(b) * Hq + h) * nsplit + split;
-    part_o[pi * D + tid] = oo;
-    if (tid == 0) { part_ml[pi * 2] = mm; part_ml[pi * 2 + 1] = ll; }
+    if constexpr (FINAL) {
+      out[(static_cast<size_t>(b) * Hq + h) * D + tid] = f32_to_bf16(oo / ll);   // len >= 1: ll > 0
+    } else {
+      const size_t pi = (static_cast<size_t>(b) * Hq + h) * nsplit + split;
+      part_o[pi * D + tid] = oo;
+      if (tid == 0) { part_ml[pi * 2] = mm; part_ml[pi * 2 + 1] = ll; }
+    }
   }
 }
 
@@ -154,14 +159,23 @@ void launch_attn_decode(const bf16_t* q, const bf16_t* k_cache, const bf16_t* v_
                         bf16_t* out, float* part_o, float* part_ml, const int* pos, int B, int Hq,
                         int Hkv, int D, int l_max, int nsplit, float scale, hipStream_t st) {
   dim3 grid(Hq, nsplit, B), block(AD_WAVES * 64);
+  if (nsplit == 1) {   // many streams: no partial results, no second launch
+    if (D == 128)
+      hipLaunchKernelGGL((attn_decode_split_kernel<128, true>), grid, block, 0, st, q, k_cache, v_cache,
+                         part_o, part_ml, pos, Hq, Hkv, l_max, scale, out);
+    else
+      hipLaunchKernelGGL((attn_decode_split_kernel<64, true>), grid, block, 0, st, q, k_cache, v_cache,
+                         part_o, part_ml, pos, Hq, Hkv, l_max, scale, out);
+    return;
+  }
   if (D == 128) {
-    hipLaunchKernelGGL(attn_decode_split_kernel<128>, grid, block, 0, st, q, k_cache, v_cache,
-                       part_o, part_ml, pos, Hq, Hkv, l_max, scale);
+    hipLaunchKernelGGL((attn_decode_split_kernel<128, false>), grid, block, 0, st, q, k_cache, v_cache,
+                       part_o, part_ml, pos, Hq, Hkv, l_max, scale, out);
     hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(Hq, B), dim3(128), 0, st, part_o,
                        part_ml, out, Hq, nsplit);
   } else {
-    hipLaunchKernelGGL(attn_decode_split_kernel<64>, grid, block, 0, st, q, k_cache, v_cache,
-                       part_o, part_ml, pos, Hq, Hkv, l_max, scale);
+    hipLaunchKernelGGL((attn_decode_split_kernel<64, false>), grid, block, 0, st, q, k_cache, v_cache,
+                       part_o, part_ml, pos, Hq, Hkv, l_max, scale, out);
     hipLaunchKernelGGL(attn_decode_combine_kernel<64>, dim3(Hq, B), dim3(64), 0, st, part_o,
                        part_ml, out, Hq, nsplit);
   }

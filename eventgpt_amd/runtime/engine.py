@@ -329,12 +329,17 @@ class GenerationEngine:
     @staticmethod
     def kv_splits(streams: int, heads: int) -> int:
         """KV splits of the decode attention (one block per stream, head and split): 16 for one or two
-        streams, from three on the power of two that makes about 512 blocks.  7B decode step at a
-        636-token context, ms, 16 splits against this choice: 4 streams 3.35 / 3.31, 8 streams 3.95 / 3.85,
-        16 streams 4.48 / 4.42, 32 streams 5.66 / 5.59 (two streams: 8 splits 2.766, 16 splits 2.755)."""
+        streams; from three on the power of two that makes about 512 blocks, and one split -- the block writes
+        the output row itself, no partial results and no merge launch -- once streams x heads fill the CUs.
+        7B decode step at a 636-token context, ms, 16 splits against this choice: 4 streams 3.35 / 3.30,
+        8 streams 3.95 / 3.81, 16 streams 4.48 / 4.33, 32 streams 5.66 / 5.49 (two streams: 8 splits 2.766,
+        16 splits 2.755; four streams with one split 3.36)."""
         if streams <= 2:
             return 16
-        want = max(1, 512 // max(1, streams * heads))
+        blocks = max(1, streams * heads)
+        if blocks >= 256:
+            return 1
+        want = 512 // blocks
         return min(16, 1 << (want.bit_length() - 1))
 
     def _gemv_rows_ok(self, rows: int) -> bool:

@@ -38,6 +38,6 @@ def test_decode_attention_for_every_split_count(B, Hq, Hkv, D):
 def test_engines_choose_splits_by_block_count():
     from eventgpt_amd.runtime.engine import GenerationEngine
     ks = GenerationEngine.kv_splits
-    assert [ks(b, 32) for b in (1, 2, 3, 4, 8, 16, 32)] == [16, 16, 4, 4, 2, 1, 1]
-    assert [ks(32, h) for h in (4, 8, 16)] == [4, 2, 1]          # tensor-parallel ranks hold fewer heads
+    assert [ks(b, 32) for b in (1, 2, 3, 4, 8, 16, 32)] == [16, 16, 4, 4, 1, 1, 1]
+    assert [ks(32, h) for h in (4, 8, 16)] == [4, 1, 1]          # tensor-parallel ranks hold fewer heads
     assert ks(4, 4) == 16
