@@ -613,6 +613,116 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Up to 32 rows against a weight matrix, fp32 split-K slabs out (batched decode steps, verify passes): the
+// product is a stream of the weights.  The 32 x 64 configuration of the kernel above fetches 128 bytes of each
+// of 64 weight rows per K-tile, the next 128 bytes of the same rows a K-tile later; this one takes K-tiles of
+// 128, so a staging instruction reads 4 rows x 256 contiguous bytes (16 lanes per row; the 16-byte chunks of a
+// row are permuted by chunk ^ (row & 15), which puts the 16 rows of an MFMA fragment read on 16 different
+// 16-byte slots of the 256-byte bank row).  Three stages of 24 KB, two workgroups per CU.
+constexpr int FR_BK = 128, FR_W_BYTES = 64 * FR_BK * 2;
+
+// (a 16-row x image for up to 16 rows and four stages instead of three measure within 2 % of this; four stages
+// with the 32-row image, one workgroup per CU, 10 % behind)
+__global__ __launch_bounds__(256) void gemm_fewrow_kernel(GemmParams p) {
+  constexpr int AM = 32, STAGES = 3;   // rows of the x image, K-tiles in the ring
+  constexpr int A_BYTES = AM * FR_BK * 2, STAGE = A_BYTES + FR_W_BYTES;
+  constexpr int TM = AM / 16;      // 16-row blocks of x
+  constexpr int AI = AM / 16;      // x staging instructions per wave (4 rows each, shared by the four waves)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (p.N + 63) / 64;
+  const int bid = xcd_remap(blockIdx.x, tiles_n * p.splitk);
+  const int tile = bid / p.splitk, ksplit = bid % p.splitk;   // the splits of a tile are neighbours
+  const int n0 = tile * 64;
+  const int k_begin = ksplit * p.k_per_split;
+  const int k_len = min(p.k_per_split, p.K - k_begin);
+  const int nk = k_len / FR_BK;
+
+  const int r4 = lane >> 4, slot = lane & 15;
+  int voff_a[AI], voff_w[4];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = (wid * AI + i) * 4 + r4;
+    voff_a[i] = (row * p.lda + ((slot ^ (row & 15)) * 8)) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wid * 4 + i) * 4 + r4;
+    voff_w[i] = ((n0 + row) * p.ldw + ((slot ^ (row & 15)) * 8)) * 2;
+  }
+  // rows past M / N lie past the descriptor's range and arrive as zeros
+  const long long bytes_a = 2ll * p.M * p.lda, bytes_w = 2ll * p.N * p.ldw;
+  auto stage = [&](int buf, int kt) {
+    unsigned char* base = smem + buf * STAGE;
+    const long long adv = 2ll * (k_begin + kt * FR_BK);
+    const long long left_a = bytes_a - adv, left_w = bytes_w - adv;
+    const int lim_a = static_cast<int>(left_a > 0 ? left_a : 0), lim_w = static_cast<int>(left_w > 0 ? left_w : 0);
+    const unsigned char* src_a = reinterpret_cast<const unsigned char*>(p.A) + adv;
+    const unsigned char* src_w = reinterpret_cast<const unsigned char*>(p.W) + adv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) buffer_to_lds16(src_w, lim_w, base + A_BYTES + (wid * 4 + i) * 1024, voff_w[i]);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) buffer_to_lds16(src_a, lim_a, base + (wid * AI + i) * 1024, voff_a[i]);
+  };
+
+  f32x4_t acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fq = lane >> 4;
+  constexpr int G = 4 + AI;   // staging instructions per wave and stage
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) stage(s, s);
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = min(STAGES - 2, nk - 1 - kt);   // younger tiles that may still be on their way
+    if (ahead <= 0) wait_vm<0>();
+    else if (ahead == 1) wait_vm<G>();
+    else wait_vm<2 * G>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + STAGES - 1 < nk) {
+      int nb = cur + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      stage(nb, kt + STAGES - 1);
+    }
+    const unsigned char* a_img = smem + cur * STAGE + frow * 256;
+    const unsigned char* w_img = smem + cur * STAGE + A_BYTES + (wid * 16 + frow) * 256;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int off = ((ks * 4 + fq) ^ frow) * 16;
+      const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(w_img + off);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(a_img + i * 16 * 256 + off);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[i], 0, 0, 0);
+      }
+    }
+    cur = cur + 1 == STAGES ? 0 : cur + 1;
+  }
+
+  // a lane holds 4 consecutive columns of one row: one 16-byte store per 16 x 16 block
+  float* slab = p.partial + static_cast<size_t>(ksplit) * p.M * p.N;
+  const int n = n0 + wid * 16 + fq * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = i * 16 + frow;
+    if (m < p.M && n < p.N) *reinterpret_cast<f32x4_t*>(slab + static_cast<size_t>(m) * p.N + n) = acc[i];
+  }
+}
+
+static void launch_fewrow(const GemmParams& p, hipStream_t st) {
+  constexpr size_t smem = 3 * (32 * FR_BK * 2 + FR_W_BYTES);
+  static const bool attr = [] {   // 72 KB: more than a launch may ask for without opting in
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fewrow_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)) == hipSuccess;
+  }();
+  (void)attr;
+  const int tiles_n = (p.N + 63) / 64;
+  hipLaunchKernelGGL(gemm_fewrow_kernel, dim3(tiles_n * p.splitk), dim3(256), smem, st, p);
+}
+
+// ---------------------------------------------------------------------------------------
 // 256 x 256 x 64 tile, 8 waves (2 x 4, each 128 x 64 of C), one workgroup per CU: the kernel
 // for GEMMs with thousands of rows.  The 4-wave kernel above stops near 900 TFLOP/s however it
 // is pipelined, because one wave per SIMD has to alternate between feeding the LDS pipe and
@@ -1354,6 +1464,18 @@ int launch_gemm_partial(const bf16_t* A, const bf16_t* W, float* partial, int M,
                nullptr, 1, K, partial, 1, K, K};
   int splitk = gemm_splitk_slabs(M, N, K);
   if (max_split > 0 && splitk > max_split) splitk = max_split;
+  // up to 32 rows: the weight-streaming kernel (EVGPT_FEWROW_GEMM=0: the 32 x 64 tile of the general kernel).
+  // Per layer of the 7B decoder at 32 / 6 rows: 88.3 -> 84.1 / 80.4 -> 77.1 us; decode step at 8 / 32 streams
+  // 3.82 -> 3.70 / 5.50 -> 5.39 ms
+  static const bool fewrow = [] { const char* e = getenv("EVGPT_FEWROW_GEMM"); return !(e && e[0] == '0'); }();
+  if (fewrow && M <= 32 && g_forced_cfg < 0 && K % FR_BK == 0 && N % 4 == 0 && lda % 8 == 0 && ldw % 8 == 0) {
+    const int ksteps = K / FR_BK;
+    if (splitk > ksteps) splitk = ksteps;
+    p.k_per_split = ((ksteps + splitk - 1) / splitk) * FR_BK;
+    p.splitk = (K + p.k_per_split - 1) / p.k_per_split;
+    launch_fewrow(p, st);
+    return p.splitk;
+  }
   if (splitk > 1) {
     const int ksteps = K / 64;
     p.k_per_split = ((ksteps + splitk - 1) / splitk) * 64;
