@@ -171,7 +171,10 @@ def test_attention_against_cache(dev, D, Hq, Hkv, Sq, kv, Lmax):
 
 # ---- few-row projections: split-K slabs + fused consumers (verify / batched decode)
 @pytest.mark.parametrize("M,N,K", [(6, 4096, 4096), (32, 1536, 512), (2, 4096, 11008), (17, 22016, 4096),
-                                   (32, 4096, 1408), (32, 2816, 4096), (32, 4096, 512)])
+                                   (32, 4096, 1408), (32, 2816, 4096), (32, 4096, 512),
+                                   # column counts that end inside a 64-column tile, one or two K-tiles of 128,
+                                   # a contraction the 128-deep kernel does not take (192)
+                                   (5, 1000, 1024), (20, 4104, 256), (32, 72, 128), (9, 520, 192)])
 def test_linear_partial_sums_to_linear(dev, M, N, K):
     raw = _hip().raw
     x, w = _rand(M, K, dev=dev, scale=0.5), _rand(N, K, dev=dev, scale=0.05, seed=1)
